@@ -1,0 +1,337 @@
+/*
+ * rrtmgp_hip.h — C ABI of libhip_rrtmgp.so, the MI355X (gfx950) device back end
+ * for RRTMGP.jl's per-column radiative-transfer hot path.
+ *
+ * The reference has no FFI: its device back end is selected by Julia multiple
+ * dispatch on `context.device`.  Each entry point below
+ * replaces one device method of ext/RRTMGPCUDAExt.jl and the files under ext/cuda; the
+ * reference method it stands in for is cited next to it as file:line relative
+ * to the reference tree.  The Julia-side binding (`ccall`) a maintainer would
+ * add is shown in INTEGRATION.md and ext/RRTMGPHIPExt.jl.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *  - All arrays use the reference's own in-memory layouts (Julia column-major;
+ *    the FIRST listed dimension is fastest).  Index tables are Julia `Int`
+ *    (int64_t) and 1-based, exactly as the reference structs hold them.
+ *  - `ftype` is sizeof(FT): 4 = Float32, 8 = Float64.  `const void*` arrays
+ *    hold FT elements.
+ *  - Vertical index 1 (C offset 0) is the surface, nlev = nlay+1 the top.
+ *  - Lookup tables are always HOST pointers; they are re-laid-out
+ *    (g-point-innermost) and uploaded once by *_create, mirroring the one-off
+ *    `DA(...)` uploads in ext/lookup_constructors.jl:83,407,727,18.
+ *  - State / boundary-condition / flux arrays are host OR device pointers as
+ *    declared by `mem` in each struct (device pointers are used in place; host
+ *    pointers are staged through the workspace's own HBM mirrors).
+ *  - Every function returns 0 on success or a negative RRTMGP_E* code;
+ *    rrtmgp_hip_last_error() gives the message.  Like the reference kernels,
+ *    out-of-range physical inputs are clamped, never rejected.
+ *  - A workspace may be used by one host thread at a time; different
+ *    workspaces are independent.  Calls are stream-ordered on the workspace
+ *    stream and block until results are in the caller's arrays only when the
+ *    arrays are host memory.
+ */
+#ifndef RRTMGP_HIP_H
+#define RRTMGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTMGP_F32 4
+#define RRTMGP_F64 8
+
+#define RRTMGP_MEM_HOST 0
+#define RRTMGP_MEM_DEVICE 1
+
+/* flux array layouts */
+#define RRTMGP_LAYOUT_NCOL_NLEV 0 /* (ncol, nlev): FluxLW/FluxSW on a GPU device, Fluxes.jl:45-49 */
+#define RRTMGP_LAYOUT_NLEV_NCOL 1 /* (nlev, ncol): FluxPresentation, Fluxes.jl:384 */
+
+#define RRTMGP_VMR_GM 0   /* VmrGM, VolumeMixingRatios.jl:34-46 */
+#define RRTMGP_VMR_FULL 1 /* Vmr,   VolumeMixingRatios.jl:75-80 */
+
+#define RRTMGP_OK 0
+#define RRTMGP_EINVAL -1   /* bad argument / inconsistent dimensions */
+#define RRTMGP_ENODEV -2   /* no usable HIP device */
+#define RRTMGP_EHIP -3     /* HIP runtime error */
+#define RRTMGP_ENOMEM -4
+#define RRTMGP_EUNSUPPORTED -5
+
+#define RRTMGP_N_AEROSOLS 15 /* src/api/aerosols.jl:18-34 */
+
+/* ---- lookup tables (reference in-memory form) -------------------------- */
+
+/* LookUpMinor, src/optics/LookUpTables.jl:36-56 */
+typedef struct rrtmgp_minor_desc {
+    int64_t n_min_absrb;    /* size(gasdata, 2) */
+    int64_t n_contrib;      /* size(kminor, 3) */
+    const int64_t *bnd_st;  /* (n_bnd+1)  1-based start into gasdata columns */
+    const int64_t *gpt_st;  /* (n_gpt+1)  1-based start into kminor axis 3 */
+    const int64_t *gasdata; /* (4, n_min_absrb): gas idx, scaling-gas idx, scales_with_density, scale_by_complement */
+    const void *kminor;     /* FT (n_eta, n_t_ref, n_contrib) */
+} rrtmgp_minor_desc;
+
+/* LookUpLW (LookUpTables.jl:130-143) and LookUpSW (:185-201) */
+typedef struct rrtmgp_gas_lookup_desc {
+    int32_t ftype;
+    int32_t is_sw;
+    int64_t n_gpt;    /* 256 LW / 224 SW in rrtmgp-data v1.9 */
+    int64_t n_bnd;
+    int64_t n_eta;    /* size(kmajor, 1) = 9 */
+    int64_t n_p_ref;  /* length(ln_p_ref) = 59; size(kmajor, 2) = n_p_ref + 1 */
+    int64_t n_t_ref;  /* 14 */
+    int64_t n_gases;  /* size(vmr_ref, 2) = ngas + 1 (slot 1 = dry air) */
+    int64_t n_t_plnk; /* LW: length(t_planck) = 196 */
+    int64_t idx_h2o;
+    double p_ref_tropo;
+    double p_ref_min;
+    double t_ref_min;
+    double t_ref_max;
+    double solar_src_tot;        /* SW */
+    const int64_t *key_species;  /* (2, 2, n_bnd) */
+    const int64_t *major_gpt2bnd;/* (n_gpt) */
+    const void *kmajor;          /* FT (n_eta, n_p_ref+1, n_t_ref, n_gpt) */
+    const void *planck_fraction; /* LW: FT, same shape as kmajor */
+    const void *t_planck;        /* LW: FT (n_t_plnk) */
+    const void *tot_planck;      /* LW: FT (n_t_plnk, n_bnd) */
+    const void *ln_p_ref;        /* FT (n_p_ref) */
+    const void *t_ref;           /* FT (n_t_ref) */
+    const void *vmr_ref;         /* FT (2, n_gases, n_t_ref) */
+    rrtmgp_minor_desc minor_lower;
+    rrtmgp_minor_desc minor_upper;
+    const void *rayl_lower;       /* SW: FT (n_eta, n_t_ref, n_gpt) */
+    const void *rayl_upper;       /* SW */
+    const void *solar_src_scaled; /* SW: FT (n_gpt) */
+} rrtmgp_gas_lookup_desc;
+
+/* LookUpCld, LookUpTables.jl:239-284 */
+typedef struct rrtmgp_cloud_lookup_desc {
+    int32_t ftype;
+    int32_t _pad;
+    int64_t nband, nrghice, nsize_liq, nsize_ice; /* dims[1:4] */
+    const void *bounds;  /* FT (4): radliq_lwr, radliq_upr, radice_lwr, radice_upr */
+    const void *liqdata; /* FT (3*nsize_liq, nband): ext | ssa | asy stacked */
+    const void *icedata; /* FT (3*nsize_ice, nband, nrghice) */
+} rrtmgp_cloud_lookup_desc;
+
+/* LookUpAerosolMerra, LookUpTables.jl:312-325 */
+typedef struct rrtmgp_aerosol_lookup_desc {
+    int32_t ftype;
+    int32_t _pad;
+    int64_t nband, nbin, nrh;
+    int64_t iband_550nm;          /* 0 if none */
+    const void *size_bin_limits;  /* FT (2, nbin) */
+    const void *rh_levels;        /* FT (nrh) */
+    const void *dust;             /* FT (3, nbin, nband) */
+    const void *sea_salt;         /* FT (3, nrh, nbin, nband) */
+    const void *sulfate;          /* FT (3, nrh, nband) */
+    const void *black_carbon_rh;  /* FT (3, nrh, nband) */
+    const void *black_carbon;     /* FT (3, nband) */
+    const void *organic_carbon_rh;/* FT (3, nrh, nband) */
+    const void *organic_carbon;   /* FT (3, nband) */
+} rrtmgp_aerosol_lookup_desc;
+
+/* ---- caller-owned state, boundary conditions, outputs ------------------- */
+
+/* AtmosphericState (+ CloudState, AerosolState, Vmr/VmrGM),
+ * src/optics/AtmosphericStates.jl:70-82,236-248,292-298 */
+typedef struct rrtmgp_atmos_state {
+    int32_t mem;      /* RRTMGP_MEM_HOST / RRTMGP_MEM_DEVICE for every pointer below */
+    int32_t vmr_kind; /* RRTMGP_VMR_GM / RRTMGP_VMR_FULL */
+    int64_t ncol;
+    int64_t nlay;
+    int64_t ngas;          /* GM: length(vmr); FULL: size(vmr, 1) */
+    const void *layerdata; /* FT (4, nlay, ncol): col_dry, p_lay, t_lay, rel_hum */
+    const void *p_lev;     /* FT (nlev, ncol); read only by compute_col_gas */
+    const void *t_lev;     /* FT (nlev, ncol) */
+    const void *t_sfc;     /* FT (ncol) */
+    const void *lat;       /* FT (ncol) or NULL */
+    const void *vmr_h2o;   /* GM: FT (nlay, ncol) */
+    const void *vmr_o3;    /* GM: FT (nlay, ncol) */
+    const void *vmr;       /* GM: FT (ngas); FULL: FT (ngas, nlay, ncol) */
+    /* CloudState; all NULL when the solve has no clouds */
+    const void *cld_r_eff_liq; /* FT (nlay, ncol) [um] */
+    const void *cld_r_eff_ice;
+    const void *cld_path_liq;  /* [g/m2] */
+    const void *cld_path_ice;
+    const void *cld_frac;
+    void *cld_cover_lw; /* out FT (ncol) or NULL */
+    void *cld_cover_sw; /* out FT (ncol) or NULL */
+    int64_t ice_rgh;    /* 1..3 */
+    /* AerosolState; NULL when the solve has no aerosols */
+    const void *aero_size; /* FT (15, nlay, ncol) [um] */
+    const void *aero_mass; /* FT (15, nlay, ncol) [kg/m2] */
+    void *aod_sw_ext;      /* out FT (ncol) or NULL */
+    void *aod_sw_sca;      /* out FT (ncol) or NULL */
+} rrtmgp_atmos_state;
+
+/* LwBCs, src/optics/BCs.jl:17-26 */
+typedef struct rrtmgp_lw_bcs {
+    int32_t mem;
+    int32_t _pad;
+    const void *sfc_emis; /* FT (nbnd_lw, ncol) */
+    const void *inc_flux; /* FT (ncol, ngpt) or NULL */
+} rrtmgp_lw_bcs;
+
+/* SwBCs, src/optics/BCs.jl:40-59 (inc_flux_diffuse is stored but never read
+ * by the reference solver, shortwave_2stream.jl:331, so it is not passed) */
+typedef struct rrtmgp_sw_bcs {
+    int32_t mem;
+    int32_t _pad;
+    const void *cos_zenith;      /* FT (ncol) */
+    const void *toa_flux;        /* FT (ncol) */
+    const void *sfc_alb_direct;  /* FT (nbnd_sw, ncol) */
+    const void *sfc_alb_diffuse; /* FT (nbnd_sw, ncol) */
+} rrtmgp_sw_bcs;
+
+/* FluxLW / FluxSW broadband accumulators, src/optics/Fluxes.jl:93-149 */
+typedef struct rrtmgp_flux_out {
+    int32_t mem;
+    int32_t layout;    /* RRTMGP_LAYOUT_* */
+    void *flux_up;     /* FT, ncol*nlev */
+    void *flux_dn;
+    void *flux_net;
+    void *flux_dn_dir; /* SW only; NULL for LW */
+} rrtmgp_flux_out;
+
+/* Per-call options. */
+typedef struct rrtmgp_solve_opts {
+    int32_t n_gauss_angles;      /* LW no-scattering: 1..4 (AngularDiscretizations.jl:34-63) */
+    int32_t metric_mem;          /* mem kind of metric_scaling */
+    const void *metric_scaling;  /* FT (nlev, ncol) or NULL; apply_metric_scaling!, Fluxes.jl:295-304 */
+    uint64_t seed;               /* McICA stream key (see rrtmgp_hip_mcica_uniform) */
+    int64_t col_offset;          /* global index of column 0 of this shard: keys the
+                                    McICA stream so results do not depend on how
+                                    columns are sharded across GPUs */
+} rrtmgp_solve_opts;
+
+/* Gray-atmosphere state, src/optics/gray_atmospheric_states.jl:100-128 */
+typedef struct rrtmgp_gray_state {
+    int32_t mem;
+    int32_t otp_kind; /* 0 = GrayOpticalThicknessSchneider2004, 1 = ...OGorman2008 */
+    int64_t ncol;
+    int64_t nlay;
+    const void *lat;   /* FT (ncol) degrees */
+    const void *p_lay; /* FT (nlay, ncol) */
+    const void *p_lev; /* FT (nlev, ncol) */
+    const void *t_lay; /* FT (nlay, ncol) */
+    const void *t_lev; /* FT (nlev, ncol) */
+    const void *t_sfc; /* FT (ncol) */
+    double otp[5];     /* Schneider: alpha, te, tt, dt ; OGorman: alpha, fl, tau_e, tau_p, tau_0 */
+    double stefan;     /* RP.Stefan(param_set) */
+} rrtmgp_gray_state;
+
+/* RRTMGPParameters subset used on the device path, src/Parameters.jl:6-14 */
+typedef struct rrtmgp_params {
+    double grav, molmass_dryair, molmass_water, gas_constant, kappa_d, stefan, avogad;
+} rrtmgp_params;
+
+typedef struct rrtmgp_lookup rrtmgp_lookup;       /* opaque device-resident lookup */
+typedef struct rrtmgp_workspace rrtmgp_workspace; /* opaque per-(ncol,nlay,FT) scratch */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Number of visible HIP devices, or RRTMGP_ENODEV. */
+int rrtmgp_hip_device_count(void);
+
+/* One-off table uploads; replace DA(...) in ext/lookup_constructors.jl:83 (LookUpLW),
+ * :407 (LookUpSW), :727 (LookUpCld), :18 (LookUpAerosolMerra). */
+int rrtmgp_hip_gas_lookup_create(const rrtmgp_gas_lookup_desc *desc, int device, rrtmgp_lookup **out);
+int rrtmgp_hip_cloud_lookup_create(const rrtmgp_cloud_lookup_desc *desc, int device, rrtmgp_lookup **out);
+int rrtmgp_hip_aerosol_lookup_create(const rrtmgp_aerosol_lookup_desc *desc, int device, rrtmgp_lookup **out);
+int rrtmgp_hip_lookup_destroy(rrtmgp_lookup *lk);
+
+/* Scratch that the reference keeps in op/src/fluxb/state_cache/masks
+ * (src/rte/RTE.jl:53,111,177,229); allocated once, zero allocation per solve
+ * (update_fluxes.jl:215-218). */
+int rrtmgp_hip_workspace_create(int device, int64_t ncol, int64_t nlay, int32_t ftype, rrtmgp_workspace **out);
+int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws);
+/* Run this workspace's launches on an existing hipStream_t (e.g. torch's
+ * current stream); NULL restores the workspace's own stream. */
+int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream);
+/* Block until everything queued on the workspace stream has finished. */
+int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws);
+/* Milliseconds the solver kernel(s) of the most recent solve took on the
+ * device (HIP events on the workspace stream); synchronizes. */
+int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms);
+
+/* ---- spectral solvers (K1-K4 of SURVEY.md §2.2) -------------------------- */
+
+/* rte_lw_2stream_solve!(device::CUDADevice, flux, flux_lw, band_flux, src_lw, bcs_lw, op, as,
+ *   state_cache, lookup_lw, lookup_lw_cld, lookup_lw_aero)  ext/cuda/rte_longwave_2stream.jl:48
+ * (+ apply_metric_scaling!, src/rte/RTESolver.jl:140). cld / aero may be NULL. */
+int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw,
+                                    const rrtmgp_lookup *lookup_lw_cld, const rrtmgp_lookup *lookup_lw_aero,
+                                    const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts);
+
+/* rte_lw_noscat_solve!(device::CUDADevice, ..., angle_disc, ...)  ext/cuda/rte_longwave_noscat.jl:54 */
+int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw,
+                                   const rrtmgp_lookup *lookup_lw_cld, const rrtmgp_lookup *lookup_lw_aero,
+                                   const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                                   const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts);
+
+/* rte_sw_2stream_solve!(device::CUDADevice, ...)  ext/cuda/rte_shortwave_2stream.jl:58 */
+int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw,
+                                    const rrtmgp_lookup *lookup_sw_cld, const rrtmgp_lookup *lookup_sw_aero,
+                                    const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
+                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts);
+
+/* rte_sw_noscat_solve!(device::CUDADevice, ...)  ext/cuda/rte_shortwave_noscat.jl:54 */
+int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw,
+                                   const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
+                                   const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts);
+
+/* ---- gray solvers (K5-K8) ------------------------------------------------ */
+
+/* ext/cuda/rte_longwave_2stream.jl:1, rte_longwave_noscat.jl:1 */
+int rrtmgp_hip_rte_lw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
+                                         const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
+                                         const rrtmgp_solve_opts *opts);
+int rrtmgp_hip_rte_lw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
+                                        const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
+                                        const rrtmgp_solve_opts *opts);
+/* ext/cuda/rte_shortwave_2stream.jl:1, rte_shortwave_noscat.jl:1 */
+int rrtmgp_hip_rte_sw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
+                                         const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux,
+                                         const rrtmgp_solve_opts *opts);
+int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
+                                        const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux,
+                                        const rrtmgp_solve_opts *opts);
+
+/* ---- state preparation (K9, K10) ----------------------------------------- */
+
+/* compute_col_gas!(device::CUDADevice, p_lev, col_dry, param_set, vmr_h2o, lat)  ext/cuda/optics.jl:2
+ * p_lev (nlev, ncol) -> col_dry (nlay, ncol); vmr_h2o (nlay, ncol) or NULL; lat (ncol) or NULL. */
+int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry,
+                               const rrtmgp_params *params, const void *vmr_h2o, const void *lat);
+
+/* compute_relative_humidity!(device::CUDADevice, rh, p_lay, t_lay, param_set, vmr_h2o)  ext/cuda/optics.jl:35 */
+int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
+                                         const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o);
+
+/* ---- McICA stream -------------------------------------------------------- */
+
+/* The reference draws Random.rand() (Float64) per (g-point, column) inside
+ * build_cloud_mask! (src/optics/cloud_optics.jl:279,291) and documents the
+ * stream as device-dependent and not reproducible.  This back end defines a
+ * counter-based stream instead: draw number `draw` of g-point `igpt` (1-based)
+ * of global column `gcol` (1-based) in band set `is_sw` under `seed` is
+ * rrtmgp_hip_mcica_uniform(...) in [0, 1).  Host-callable so tests can pin it. */
+double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32_t is_sw, int32_t draw);
+
+/* ---- diagnostics ---------------------------------------------------------- */
+
+/* Copies the calling thread's last error message (NUL-terminated) into buf. */
+int rrtmgp_hip_last_error(char *buf, size_t n);
+/* "major.minor.patch" */
+const char *rrtmgp_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRTMGP_HIP_H */
