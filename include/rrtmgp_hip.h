@@ -330,6 +330,11 @@ double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32
 int rrtmgp_hip_last_error(char *buf, size_t n);
 /* "major.minor.patch" */
 const char *rrtmgp_hip_version(void);
+/* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,
+ * 1 gas_lookup_desc, 2 cloud_lookup_desc, 3 aerosol_lookup_desc, 4 atmos_state, 5 lw_bcs,
+ * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params); -1 otherwise.  Lets a
+ * foreign-language binding verify its struct mirror at load time. */
+int rrtmgp_hip_abi_sizeof(int which);
 
 #ifdef __cplusplus
 }

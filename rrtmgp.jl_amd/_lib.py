@@ -1,0 +1,108 @@
+"""Loader for libhip_rrtmgp.so (the HIP back end).  There is no CPU fallback: if the
+library is missing, cannot be loaded, or sees no GPU, the product path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhip_rrtmgp.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+_P = C.c_void_p
+_SOLVE_SPECTRAL = [_P, _P, _P, _P, C.POINTER(_abi.AtmosState), _P, C.POINTER(_abi.FluxOut), C.POINTER(_abi.SolveOpts)]
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "rrtmgp_hip_device_count": (C.c_int, []),
+    "rrtmgp_hip_gas_lookup_create": (C.c_int, [C.POINTER(_abi.GasLookupDesc), C.c_int, C.POINTER(_P)]),
+    "rrtmgp_hip_cloud_lookup_create": (C.c_int, [C.POINTER(_abi.CloudLookupDesc), C.c_int, C.POINTER(_P)]),
+    "rrtmgp_hip_aerosol_lookup_create": (C.c_int, [C.POINTER(_abi.AerosolLookupDesc), C.c_int, C.POINTER(_P)]),
+    "rrtmgp_hip_lookup_destroy": (C.c_int, [_P]),
+    "rrtmgp_hip_workspace_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int32, C.POINTER(_P)]),
+    "rrtmgp_hip_workspace_destroy": (C.c_int, [_P]),
+    "rrtmgp_hip_workspace_set_stream": (C.c_int, [_P, _P]),
+    "rrtmgp_hip_workspace_synchronize": (C.c_int, [_P]),
+    "rrtmgp_hip_workspace_last_kernel_ms": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "rrtmgp_hip_rte_lw_2stream_solve": (C.c_int, _SOLVE_SPECTRAL),
+    "rrtmgp_hip_rte_lw_noscat_solve": (C.c_int, _SOLVE_SPECTRAL),
+    "rrtmgp_hip_rte_sw_2stream_solve": (C.c_int, _SOLVE_SPECTRAL),
+    "rrtmgp_hip_rte_sw_noscat_solve": (C.c_int, [_P, _P, C.POINTER(_abi.AtmosState), _P, C.POINTER(_abi.FluxOut),
+                                                 C.POINTER(_abi.SolveOpts)]),
+    "rrtmgp_hip_rte_lw_2stream_solve_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), _P, C.POINTER(_abi.FluxOut),
+                                                       C.POINTER(_abi.SolveOpts)]),
+    "rrtmgp_hip_rte_lw_noscat_solve_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), _P, C.POINTER(_abi.FluxOut),
+                                                      C.POINTER(_abi.SolveOpts)]),
+    "rrtmgp_hip_rte_sw_2stream_solve_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), _P, C.POINTER(_abi.FluxOut),
+                                                       C.POINTER(_abi.SolveOpts)]),
+    "rrtmgp_hip_rte_sw_noscat_solve_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), _P, C.POINTER(_abi.FluxOut),
+                                                      C.POINTER(_abi.SolveOpts)]),
+    "rrtmgp_hip_compute_col_gas": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(_abi.Params), _P, _P]),
+    "rrtmgp_hip_compute_relative_humidity": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(_abi.Params), _P]),
+    "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "rrtmgp_hip_version": (C.c_char_p, []),
+    "rrtmgp_hip_abi_sizeof": (C.c_int, [C.c_int]),
+}
+
+ABI_STRUCTS = [_abi.MinorDesc, _abi.GasLookupDesc, _abi.CloudLookupDesc, _abi.AerosolLookupDesc, _abi.AtmosState,
+               _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params]
+
+
+class RRTMGPHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libhip_rrtmgp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RRTMGPHipError("building libhip_rrtmgp.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return SO_PATH
+
+
+def lib():
+    """The loaded library with typed entry points; raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RRTMGPHipError(f"{SO_PATH} is missing: run `make -C {CSRC}` (or __graft_entry__.build()). "
+                                 "There is no CPU fallback for the product path.")
+        try:
+            L = C.CDLL(SO_PATH)
+        except OSError as e:
+            raise RRTMGPHipError(f"cannot load {SO_PATH}: {e}") from e
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        for i, st in enumerate(ABI_STRUCTS):
+            if L.rrtmgp_hip_abi_sizeof(i) != C.sizeof(st):
+                raise RRTMGPHipError(f"ABI mismatch for {st.__name__}: library {L.rrtmgp_hip_abi_sizeof(i)} bytes, "
+                                     f"binding {C.sizeof(st)} bytes")
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib().rrtmgp_hip_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RRTMGPHipError(f"{what}: {_abi.ERRORS.get(rc, rc)}: {last_error()}")
+
+
+def require_gpu() -> int:
+    n = lib().rrtmgp_hip_device_count()
+    if n <= 0:
+        raise RRTMGPHipError("no HIP device visible: " + last_error())
+    return n

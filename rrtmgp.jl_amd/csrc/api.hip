@@ -1,0 +1,722 @@
+// api.hip — host side of the C ABI declared in include/rrtmgp_hip.h:
+// lookup re-layout + upload, workspaces, host<->HBM staging, solver dispatch.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+#include "device.h"
+
+namespace rrtmgp {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return set_error(RRTMGP_EHIP, buf);
+}
+
+int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes) {
+    if ((int)ws->stage.size() <= slot) ws->stage.resize(slot + 1);
+    DeviceBuffer &b = ws->stage[slot];
+    if (b.bytes >= bytes && b.ptr) return RRTMGP_OK;
+    if (b.ptr) RR_HIP(hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.bytes = 0;
+    RR_HIP(hipMalloc(&b.ptr, bytes ? bytes : 16));
+    b.bytes = bytes;
+    return RRTMGP_OK;
+}
+
+int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
+    if (ws->scratch.bytes >= bytes && ws->scratch.ptr) return RRTMGP_OK;
+    if (ws->scratch.ptr) {
+        RR_HIP(hipStreamSynchronize(ws->stream));
+        RR_HIP(hipFree(ws->scratch.ptr));
+    }
+    ws->scratch.ptr = nullptr;
+    ws->scratch.bytes = 0;
+    RR_HIP(hipMalloc(&ws->scratch.ptr, bytes));
+    ws->scratch.bytes = bytes;
+    return RRTMGP_OK;
+}
+
+// Number of workgroups for a one-workgroup-per-column kernel: every column gets its
+// own group up to a few resident generations per CU, then groups stride over columns.
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes) {
+    if (lds_bytes > 160 * 1024) return set_error(RRTMGP_EUNSUPPORTED, "column does not fit the 160 KB LDS");
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
+    per_cu = std::min(per_cu, 2048 / threads);
+    per_cu = std::max(per_cu, 1);
+    const int cap = ws->n_cu * per_cu;
+    return std::max(1, std::min(ncol, cap));
+}
+
+// ---- upload helpers -----------------------------------------------------------------
+template <typename T>
+static int upload(rrtmgp_lookup *lk, const std::vector<T> &h, const T **out) {
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    RR_HIP(hipMalloc(&d, bytes));
+    lk->allocs.push_back(d);
+    if (!h.empty()) RR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T *)d;
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+static int upload_raw(rrtmgp_lookup *lk, const void *src, size_t n, const FT **out) {
+    std::vector<FT> h((const FT *)src, (const FT *)src + n);
+    return upload(lk, h, out);
+}
+
+#define TRY(x)            \
+    do {                  \
+        int _rc = (x);    \
+        if (_rc) return _rc; \
+    } while (0)
+
+template <typename FT>
+static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<FT> &g) {
+    const int64_t NE = d->n_eta, NP = d->n_p_ref + 1, NT = d->n_t_ref, NG = d->n_gpt, NB = d->n_bnd;
+    RR_CHECK(NE >= 2 && NP >= 3 && NT >= 2 && NG >= 1 && NB >= 1, "bad gas lookup dimensions");
+    RR_CHECK(d->kmajor && d->ln_p_ref && d->t_ref && d->vmr_ref && d->key_species && d->major_gpt2bnd,
+             "gas lookup: missing table");
+    g.is_sw = d->is_sw; g.n_gpt = (int)NG; g.n_bnd = (int)NB; g.n_eta = (int)NE; g.n_pp = (int)NP; g.n_t_ref = (int)NT;
+    g.n_gases = (int)d->n_gases; g.n_t_plnk = (int)d->n_t_plnk; g.idx_h2o = (int)d->idx_h2o;
+    g.p_ref_tropo = (FT)d->p_ref_tropo;
+    // (n_eta, n_p, n_t, n_gpt) -> [t][p][eta][gpt]
+    auto relayout4 = [&](const void *src, const FT **out) -> int {
+        const FT *s = (const FT *)src;
+        std::vector<FT> h((size_t)NE * NP * NT * NG);
+        for (int64_t gq = 0; gq < NG; gq++)
+            for (int64_t t = 0; t < NT; t++)
+                for (int64_t p = 0; p < NP; p++)
+                    for (int64_t e = 0; e < NE; e++)
+                        h[((t * NP + p) * NE + e) * NG + gq] = s[e + NE * (p + NP * (t + NT * gq))];
+        return upload(lk, h, out);
+    };
+    // (n_eta, n_t, n) -> [t][eta][perm(n)]
+    auto relayout3 = [&](const void *src, int64_t n, const std::vector<int64_t> &dst_of_src, const FT **out) -> int {
+        const FT *s = (const FT *)src;
+        std::vector<FT> h((size_t)NE * NT * std::max<int64_t>(n, 1));
+        for (int64_t c = 0; c < n; c++)
+            for (int64_t t = 0; t < NT; t++)
+                for (int64_t e = 0; e < NE; e++) h[(t * NE + e) * n + dst_of_src[c]] = s[e + NE * (t + NT * c)];
+        return upload(lk, h, out);
+    };
+    TRY(relayout4(d->kmajor, &g.kmajor));
+    g.pfrac = nullptr; g.t_planck = nullptr; g.tot_planck = nullptr;
+    if (!d->is_sw) {
+        RR_CHECK(d->planck_fraction && d->t_planck && d->tot_planck && d->n_t_plnk >= 2, "LW lookup: missing Planck tables");
+        TRY(relayout4(d->planck_fraction, &g.pfrac));
+        TRY(upload_raw<FT>(lk, d->t_planck, d->n_t_plnk, &g.t_planck));
+        TRY(upload_raw<FT>(lk, d->tot_planck, d->n_t_plnk * NB, &g.tot_planck));
+    }
+    TRY(upload_raw<FT>(lk, d->ln_p_ref, d->n_p_ref, &g.ln_p_ref));
+    TRY(upload_raw<FT>(lk, d->t_ref, NT, &g.t_ref));
+    TRY(upload_raw<FT>(lk, d->vmr_ref, 2 * d->n_gases * NT, &g.vmr_ref));
+    std::vector<int> ks(4 * NB), g2b(NG), lo(NB, -1), ng(NB, 0);
+    for (int64_t i = 0; i < 4 * NB; i++) {
+        RR_CHECK(d->key_species[i] >= 0 && d->key_species[i] < d->n_gases, "key_species out of range");
+        ks[i] = (int)d->key_species[i];
+    }
+    for (int64_t i = 0; i < NG; i++) {
+        const int64_t b = d->major_gpt2bnd[i] - 1;
+        RR_CHECK(b >= 0 && b < NB, "major_gpt2bnd out of range");
+        RR_CHECK(i == 0 || b >= d->major_gpt2bnd[i - 1] - 1, "g-points of a band must be contiguous");
+        g2b[i] = (int)b;
+        if (lo[b] < 0) lo[b] = (int)i;
+        ng[b]++;
+    }
+    TRY(upload(lk, ks, &g.key_species));
+    TRY(upload(lk, g2b, &g.gpt2bnd));
+    TRY(upload(lk, lo, &g.bnd_lo));
+    TRY(upload(lk, ng, &g.bnd_ng));
+    const rrtmgp_minor_desc *md[2] = {&d->minor_lower, &d->minor_upper};
+    for (int r = 0; r < 2; r++) {
+        const rrtmgp_minor_desc *m = md[r];
+        RR_CHECK(m->bnd_st && m->gpt_st && (m->n_min_absrb == 0 || m->gasdata), "minor lookup: missing table");
+        std::vector<int> bst(NB + 1), gd(4 * std::max<int64_t>(m->n_min_absrb, 1), 0), koff(NB, 0);
+        for (int64_t b = 0; b <= NB; b++) bst[b] = (int)(m->bnd_st[b] - 1);
+        for (int64_t i = 0; i < 4 * m->n_min_absrb; i++) gd[i] = (int)m->gasdata[i];
+        for (int64_t i = 0; i < m->n_min_absrb; i++)
+            RR_CHECK(gd[4 * i] >= 0 && gd[4 * i] < d->n_gases && gd[4 * i + 1] >= 0 && gd[4 * i + 1] < d->n_gases,
+                     "minor gas index out of range");
+        // reference order: contributor (gpt_st[g] - 1) + i ; device order: koff[b] + i*ng_b + (g - lo_b)
+        std::vector<int64_t> dst(std::max<int64_t>(m->n_contrib, 1), 0);
+        int64_t off = 0;
+        for (int64_t b = 0; b < NB; b++) {
+            const int64_t nb = bst[b + 1] - bst[b];
+            RR_CHECK(nb >= 0, "minor bnd_st must be non-decreasing");
+            koff[b] = (int)off;
+            lk->max_minor = std::max<int>(lk->max_minor, (int)nb);
+            for (int64_t gi = 0; gi < ng[b]; gi++) {
+                const int64_t gq = lo[b] + gi;
+                RR_CHECK(m->gpt_st[gq + 1] - m->gpt_st[gq] == nb, "minor gpt_st inconsistent with bnd_st");
+                for (int64_t i = 0; i < nb; i++) {
+                    const int64_t src = m->gpt_st[gq] - 1 + i;
+                    RR_CHECK(src >= 0 && src < m->n_contrib, "minor contributor index out of range");
+                    dst[src] = off + i * ng[b] + gi;
+                }
+            }
+            off += nb * ng[b];
+        }
+        RR_CHECK(off == m->n_contrib || m->n_contrib == 0 || off <= m->n_contrib, "minor contributor count mismatch");
+        g.m_ncontrib[r] = (int)std::max<int64_t>(m->n_contrib, 1);
+        TRY(upload(lk, bst, &g.m_bnd_st[r]));
+        TRY(upload(lk, gd, &g.m_gasdata[r]));
+        TRY(upload(lk, koff, &g.m_koff[r]));
+        if (m->n_contrib > 0) {
+            RR_CHECK(m->kminor, "minor lookup: missing kminor");
+            TRY(relayout3(m->kminor, m->n_contrib, dst, &g.m_kminor[r]));
+        } else {
+            std::vector<FT> z((size_t)NE * NT, FT(0));
+            TRY(upload(lk, z, &g.m_kminor[r]));
+        }
+    }
+    g.rayl[0] = g.rayl[1] = nullptr;
+    g.solar_src_scaled = nullptr;
+    if (d->is_sw) {
+        RR_CHECK(d->rayl_lower && d->rayl_upper && d->solar_src_scaled, "SW lookup: missing Rayleigh / solar tables");
+        std::vector<int64_t> ident(NG);
+        for (int64_t i = 0; i < NG; i++) ident[i] = i;
+        TRY(relayout3(d->rayl_lower, NG, ident, &g.rayl[0]));
+        TRY(relayout3(d->rayl_upper, NG, ident, &g.rayl[1]));
+        TRY(upload_raw<FT>(lk, d->solar_src_scaled, NG, &g.solar_src_scaled));
+    }
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+static int build_cld(rrtmgp_lookup *lk, const rrtmgp_cloud_lookup_desc *d, DevCld<FT> &c) {
+    RR_CHECK(d->bounds && d->liqdata && d->icedata, "cloud lookup: missing table");
+    RR_CHECK(d->nsize_liq >= 2 && d->nsize_ice >= 2 && d->nband >= 1 && d->nrghice >= 1, "bad cloud lookup dimensions");
+    c.nband = (int)d->nband; c.nrghice = (int)d->nrghice; c.nsize_liq = (int)d->nsize_liq; c.nsize_ice = (int)d->nsize_ice;
+    const FT *b = (const FT *)d->bounds;
+    c.radliq_lwr = b[0]; c.radliq_upr = b[1]; c.radice_lwr = b[2]; c.radice_upr = b[3];
+    TRY(upload_raw<FT>(lk, d->liqdata, 3 * d->nsize_liq * d->nband, &c.liqdata));
+    TRY(upload_raw<FT>(lk, d->icedata, 3 * d->nsize_ice * d->nband * d->nrghice, &c.icedata));
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+static int build_aero(rrtmgp_lookup *lk, const rrtmgp_aerosol_lookup_desc *d, DevAero<FT> &a) {
+    RR_CHECK(d->size_bin_limits && d->rh_levels && d->dust && d->sea_salt && d->sulfate && d->black_carbon_rh &&
+                 d->black_carbon && d->organic_carbon_rh && d->organic_carbon,
+             "aerosol lookup: missing table");
+    RR_CHECK(d->nbin >= 1 && d->nbin <= 255 && d->nrh >= 2 && d->nband >= 1, "bad aerosol lookup dimensions");
+    a.nband = (int)d->nband; a.nbin = (int)d->nbin; a.nrh = (int)d->nrh; a.iband_550nm = (int)d->iband_550nm;
+    TRY(upload_raw<FT>(lk, d->size_bin_limits, 2 * d->nbin, &a.size_bin_limits));
+    TRY(upload_raw<FT>(lk, d->rh_levels, d->nrh, &a.rh_levels));
+    TRY(upload_raw<FT>(lk, d->dust, 3 * d->nbin * d->nband, &a.dust));
+    TRY(upload_raw<FT>(lk, d->sea_salt, 3 * d->nrh * d->nbin * d->nband, &a.sea_salt));
+    TRY(upload_raw<FT>(lk, d->sulfate, 3 * d->nrh * d->nband, &a.sulfate));
+    TRY(upload_raw<FT>(lk, d->black_carbon_rh, 3 * d->nrh * d->nband, &a.black_carbon_rh));
+    TRY(upload_raw<FT>(lk, d->black_carbon, 3 * d->nband, &a.black_carbon));
+    TRY(upload_raw<FT>(lk, d->organic_carbon_rh, 3 * d->nrh * d->nband, &a.organic_carbon_rh));
+    TRY(upload_raw<FT>(lk, d->organic_carbon, 3 * d->nband, &a.organic_carbon));
+    return RRTMGP_OK;
+}
+
+static int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_error(RRTMGP_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n) return set_error(RRTMGP_EINVAL, "device index out of range");
+    RR_HIP(hipSetDevice(device));
+    return RRTMGP_OK;
+}
+
+// ---- staging of host-memory arguments -------------------------------------------------
+enum Slot {
+    S_LAYERDATA = 0, S_TLEV, S_TSFC, S_VMR_H2O, S_VMR_O3, S_VMR, S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F,
+    S_CLD_COVER, S_AERO_SIZE, S_AERO_MASS, S_AOD_EXT, S_AOD_SCA, S_BC0, S_BC1, S_BC2, S_BC3, S_FLUX_UP, S_FLUX_DN,
+    S_FLUX_NET, S_FLUX_DIR, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_NSLOTS
+};
+
+struct Stager {
+    rrtmgp_workspace *ws;
+    struct Back { void *host; void *dev; size_t bytes; };
+    std::vector<Back> backs;
+
+    // input: returns device pointer (copying H2D if mem == host)
+    int in(int mem, int slot, const void *p, size_t bytes, const void **out) {
+        if (!p) { *out = nullptr; return RRTMGP_OK; }
+        if (mem == RRTMGP_MEM_DEVICE) { *out = p; return RRTMGP_OK; }
+        TRY(stage_ensure(ws, slot, bytes));
+        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, ws->stream));
+        *out = ws->stage[slot].ptr;
+        return RRTMGP_OK;
+    }
+    // output: returns device pointer; host copies are done by finish()
+    int out(int mem, int slot, void *p, size_t bytes, void **outp) {
+        if (!p) { *outp = nullptr; return RRTMGP_OK; }
+        if (mem == RRTMGP_MEM_DEVICE) { *outp = p; return RRTMGP_OK; }
+        TRY(stage_ensure(ws, slot, bytes));
+        *outp = ws->stage[slot].ptr;
+        backs.push_back({p, ws->stage[slot].ptr, bytes});
+        return RRTMGP_OK;
+    }
+    int finish() {
+        if (backs.empty()) return RRTMGP_OK;
+        for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ws->stream));
+        RR_HIP(hipStreamSynchronize(ws->stream));
+        return RRTMGP_OK;
+    }
+};
+
+template <typename FT>
+static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, bool use_aero, bool lw, DevState<FT> &d) {
+    const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1;
+    RR_CHECK(as->layerdata && as->t_sfc && as->vmr, "atmospheric state: missing array");
+    RR_CHECK(!lw || as->t_lev, "atmospheric state: t_lev is required for longwave");
+    d.ncol = (int)ncol; d.nlay = (int)nlay; d.ngas = (int)as->ngas; d.vmr_kind = as->vmr_kind;
+    const int mem = as->mem;
+    TRY(st.in(mem, S_LAYERDATA, as->layerdata, 4 * nlay * ncol * E, (const void **)&d.layerdata));
+    TRY(st.in(mem, S_TLEV, as->t_lev, nlev * ncol * E, (const void **)&d.t_lev));
+    TRY(st.in(mem, S_TSFC, as->t_sfc, ncol * E, (const void **)&d.t_sfc));
+    if (as->vmr_kind == RRTMGP_VMR_GM) {
+        RR_CHECK(as->vmr_h2o && as->vmr_o3, "VmrGM: vmr_h2o and vmr_o3 are required");
+        TRY(st.in(mem, S_VMR_H2O, as->vmr_h2o, nlay * ncol * E, (const void **)&d.vmr_h2o));
+        TRY(st.in(mem, S_VMR_O3, as->vmr_o3, nlay * ncol * E, (const void **)&d.vmr_o3));
+        TRY(st.in(mem, S_VMR, as->vmr, as->ngas * E, (const void **)&d.vmr));
+    } else {
+        d.vmr_h2o = d.vmr_o3 = nullptr;
+        TRY(st.in(mem, S_VMR, as->vmr, (size_t)as->ngas * nlay * ncol * E, (const void **)&d.vmr));
+    }
+    d.cld_r_eff_liq = d.cld_r_eff_ice = d.cld_path_liq = d.cld_path_ice = d.cld_frac = nullptr;
+    d.cld_cover = nullptr;
+    d.ice_rgh = (int)as->ice_rgh;
+    if (use_cld) {
+        RR_CHECK(as->cld_frac && as->cld_r_eff_liq && as->cld_r_eff_ice && as->cld_path_liq && as->cld_path_ice,
+                 "cloud lookup given but the state has no CloudState");
+        RR_CHECK(as->ice_rgh >= 1, "ice_rgh must be >= 1");
+        TRY(st.in(mem, S_CLD_RL, as->cld_r_eff_liq, nlay * ncol * E, (const void **)&d.cld_r_eff_liq));
+        TRY(st.in(mem, S_CLD_RI, as->cld_r_eff_ice, nlay * ncol * E, (const void **)&d.cld_r_eff_ice));
+        TRY(st.in(mem, S_CLD_PL, as->cld_path_liq, nlay * ncol * E, (const void **)&d.cld_path_liq));
+        TRY(st.in(mem, S_CLD_PI, as->cld_path_ice, nlay * ncol * E, (const void **)&d.cld_path_ice));
+        TRY(st.in(mem, S_CLD_F, as->cld_frac, nlay * ncol * E, (const void **)&d.cld_frac));
+        TRY(st.out(mem, S_CLD_COVER, lw ? as->cld_cover_lw : as->cld_cover_sw, ncol * E, (void **)&d.cld_cover));
+    }
+    d.aero_size = d.aero_mass = nullptr;
+    d.aod_sw_ext = d.aod_sw_sca = nullptr;
+    if (use_aero) {
+        RR_CHECK(as->aero_size && as->aero_mass, "aerosol lookup given but the state has no AerosolState");
+        const size_t n = (size_t)RRTMGP_N_AEROSOLS * nlay * ncol * E;
+        TRY(st.in(mem, S_AERO_SIZE, as->aero_size, n, (const void **)&d.aero_size));
+        TRY(st.in(mem, S_AERO_MASS, as->aero_mass, n, (const void **)&d.aero_mass));
+        if (!lw) {
+            RR_CHECK((as->aod_sw_ext == nullptr) == (as->aod_sw_sca == nullptr), "aod_sw_ext and aod_sw_sca go together");
+            TRY(st.out(mem, S_AOD_EXT, as->aod_sw_ext, ncol * E, (void **)&d.aod_sw_ext));
+            TRY(st.out(mem, S_AOD_SCA, as->aod_sw_sca, ncol * E, (void **)&d.aod_sw_sca));
+        }
+    }
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_opts *opts, size_t ncol, size_t nlev,
+                      bool sw, DevFlux<FT> &d) {
+    RR_CHECK(f && f->flux_up && f->flux_dn && f->flux_net, "flux outputs: missing array");
+    RR_CHECK(f->layout == RRTMGP_LAYOUT_NCOL_NLEV || f->layout == RRTMGP_LAYOUT_NLEV_NCOL, "bad flux layout");
+    const size_t bytes = ncol * nlev * sizeof(FT);
+    TRY(st.out(f->mem, S_FLUX_UP, f->flux_up, bytes, (void **)&d.up));
+    TRY(st.out(f->mem, S_FLUX_DN, f->flux_dn, bytes, (void **)&d.dn));
+    TRY(st.out(f->mem, S_FLUX_NET, f->flux_net, bytes, (void **)&d.net));
+    d.dir = nullptr;
+    if (sw) TRY(st.out(f->mem, S_FLUX_DIR, f->flux_dn_dir, bytes, (void **)&d.dir));
+    d.layout = f->layout;
+    d.metric = nullptr;
+    if (opts && opts->metric_scaling)
+        TRY(st.in(opts->metric_mem, S_METRIC, opts->metric_scaling, bytes, (const void **)&d.metric));
+    return RRTMGP_OK;
+}
+
+static int check_common(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, int want_sw, const rrtmgp_lookup *cld,
+                        const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as) {
+    RR_CHECK(ws && gas && as, "null argument");
+    RR_CHECK(gas->kind == LK_GAS, "expected a gas lookup");
+    RR_CHECK((want_sw ? gas->gas32.is_sw || gas->gas64.is_sw : !(gas->gas32.is_sw || gas->gas64.is_sw)),
+             "longwave / shortwave lookup mismatch");
+    RR_CHECK(gas->ftype == ws->ftype, "lookup and workspace precision differ");
+    RR_CHECK(!cld || (cld->kind == LK_CLOUD && cld->ftype == ws->ftype), "bad cloud lookup");
+    RR_CHECK(!aero || (aero->kind == LK_AEROSOL && aero->ftype == ws->ftype), "bad aerosol lookup");
+    RR_CHECK(gas->device == ws->device && (!cld || cld->device == ws->device) && (!aero || aero->device == ws->device),
+             "lookups and workspace live on different devices");
+    RR_CHECK(as->ncol == ws->ncol && as->nlay == ws->nlay, "state dimensions differ from the workspace");
+    RR_CHECK(as->ncol >= 1 && as->nlay >= 2, "need ncol >= 1 and nlay >= 2");
+    RR_HIP(hipSetDevice(ws->device));
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
+                      const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    RR_CHECK(bcs && bcs->sfc_emis, "LwBCs: sfc_emis is required");
+    RR_CHECK(!cld || cld->nband == lk.n_bnd, "cloud lookup band count differs from the gas lookup");
+    RR_CHECK(!aero || aero->nband == lk.n_bnd, "aerosol lookup band count differs from the gas lookup");
+    const int n_angles = opts ? opts->n_gauss_angles : 1;
+    RR_CHECK(twostream || (n_angles >= 1 && n_angles <= 4), "n_gauss_angles must be 1..4");
+    Stager st{ws, {}};
+    DevState<FT> ds;
+    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, true, ds));
+    const FT *emis, *inc;
+    TRY(st.in(bcs->mem, S_BC0, bcs->sfc_emis, (size_t)lk.n_bnd * as->ncol * sizeof(FT), (const void **)&emis));
+    TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
+    DevFlux<FT> fl;
+    TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl));
+    TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, fl, n_angles, opts ? opts->seed : 0,
+                      opts ? opts->col_offset : 0, max_minor));
+    return st.finish();
+}
+
+template <typename FT>
+static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
+                      const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
+                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    RR_CHECK(bcs && bcs->cos_zenith && bcs->toa_flux, "SwBCs: cos_zenith and toa_flux are required");
+    RR_CHECK(!twostream || (bcs->sfc_alb_direct && bcs->sfc_alb_diffuse), "SwBCs: surface albedos are required");
+    RR_CHECK(!cld || cld->nband == lk.n_bnd, "cloud lookup band count differs from the gas lookup");
+    RR_CHECK(!aero || aero->nband == lk.n_bnd, "aerosol lookup band count differs from the gas lookup");
+    RR_CHECK(flux && flux->flux_dn_dir, "FluxSW: flux_dn_dir is required");
+    Stager st{ws, {}};
+    DevState<FT> ds;
+    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, false, ds));
+    const FT *mu0, *toa, *adir, *adif;
+    const size_t E = sizeof(FT), ncol = as->ncol;
+    TRY(st.in(bcs->mem, S_BC0, bcs->cos_zenith, ncol * E, (const void **)&mu0));
+    TRY(st.in(bcs->mem, S_BC1, bcs->toa_flux, ncol * E, (const void **)&toa));
+    TRY(st.in(bcs->mem, S_BC2, bcs->sfc_alb_direct, (size_t)lk.n_bnd * ncol * E, (const void **)&adir));
+    TRY(st.in(bcs->mem, S_BC3, bcs->sfc_alb_diffuse, (size_t)lk.n_bnd * ncol * E, (const void **)&adif));
+    DevFlux<FT> fl;
+    TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl));
+    TRY(launch_sw<FT>(ws, twostream, lk, cld, aero, ds, mu0, toa, adir, adif, fl, opts ? opts->seed : 0,
+                      opts ? opts->col_offset : 0, max_minor));
+    return st.finish();
+}
+
+template <typename FT>
+static int solve_gray_lw_t(rrtmgp_workspace *ws, int twostream, const rrtmgp_gray_state *gs, const rrtmgp_lw_bcs *bcs,
+                           const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    const size_t E = sizeof(FT), ncol = gs->ncol, nlay = gs->nlay, nlev = nlay + 1;
+    Stager st{ws, {}};
+    const FT *lat, *p_lay, *p_lev, *t_lay, *t_lev, *t_sfc, *emis, *inc;
+    TRY(st.in(gs->mem, S_LAT, gs->lat, ncol * E, (const void **)&lat));
+    TRY(st.in(gs->mem, S_PLAY, gs->p_lay, nlay * ncol * E, (const void **)&p_lay));
+    TRY(st.in(gs->mem, S_PLEV, gs->p_lev, nlev * ncol * E, (const void **)&p_lev));
+    TRY(st.in(gs->mem, S_TLAY, gs->t_lay, nlay * ncol * E, (const void **)&t_lay));
+    TRY(st.in(gs->mem, S_TLEV, gs->t_lev, nlev * ncol * E, (const void **)&t_lev));
+    TRY(st.in(gs->mem, S_TSFC, gs->t_sfc, ncol * E, (const void **)&t_sfc));
+    TRY(st.in(bcs->mem, S_BC0, bcs->sfc_emis, ncol * E, (const void **)&emis));
+    TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, ncol * E, (const void **)&inc));
+    DevFlux<FT> fl;
+    TRY(stage_flux(st, flux, opts, ncol, nlev, false, fl));
+    GrayArgs ga;
+    ga.otp_kind = gs->otp_kind;
+    for (int i = 0; i < 5; i++) ga.otp[i] = gs->otp[i];
+    ga.stefan = gs->stefan;
+    TRY(launch_gray_lw<FT>(ws, twostream, (int)ncol, (int)nlay, ga, lat, p_lay, p_lev, t_lay, t_lev, t_sfc, emis, inc, fl));
+    return st.finish();
+}
+
+template <typename FT>
+static int solve_gray_sw_t(rrtmgp_workspace *ws, int twostream, const rrtmgp_gray_state *gs, const rrtmgp_sw_bcs *bcs,
+                           const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    const size_t E = sizeof(FT), ncol = gs->ncol, nlay = gs->nlay, nlev = nlay + 1;
+    Stager st{ws, {}};
+    const FT *p_lay, *p_lev, *mu0, *toa, *adir, *adif;
+    TRY(st.in(gs->mem, S_PLAY, gs->p_lay, nlay * ncol * E, (const void **)&p_lay));
+    TRY(st.in(gs->mem, S_PLEV, gs->p_lev, nlev * ncol * E, (const void **)&p_lev));
+    TRY(st.in(bcs->mem, S_BC0, bcs->cos_zenith, ncol * E, (const void **)&mu0));
+    TRY(st.in(bcs->mem, S_BC1, bcs->toa_flux, ncol * E, (const void **)&toa));
+    TRY(st.in(bcs->mem, S_BC2, bcs->sfc_alb_direct, ncol * E, (const void **)&adir));
+    TRY(st.in(bcs->mem, S_BC3, bcs->sfc_alb_diffuse, ncol * E, (const void **)&adif));
+    DevFlux<FT> fl;
+    TRY(stage_flux(st, flux, opts, ncol, nlev, true, fl));
+    GrayArgs ga;
+    ga.otp_kind = gs->otp_kind;
+    for (int i = 0; i < 5; i++) ga.otp[i] = gs->otp[i];
+    ga.stefan = gs->stefan;
+    TRY(launch_gray_sw<FT>(ws, twostream, (int)ncol, (int)nlay, ga, p_lay, p_lev, mu0, toa, adir, adif, fl));
+    return st.finish();
+}
+
+template <typename FT>
+static int col_gas_t(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry, const rrtmgp_params *ps,
+                     const void *vmr_h2o, const void *lat) {
+    const size_t E = sizeof(FT), ncol = ws->ncol, nlay = ws->nlay;
+    Stager st{ws, {}};
+    const FT *pl, *h2o, *la;
+    FT *cd;
+    TRY(st.in(mem, S_PLEV, p_lev, (nlay + 1) * ncol * E, (const void **)&pl));
+    TRY(st.in(mem, S_VMR_H2O, vmr_h2o, nlay * ncol * E, (const void **)&h2o));
+    TRY(st.in(mem, S_LAT, lat, ncol * E, (const void **)&la));
+    TRY(st.out(mem, S_AUX0, col_dry, nlay * ncol * E, (void **)&cd));
+    TRY(launch_col_gas<FT>(ws, (int)ncol, (int)nlay, pl, cd, *ps, h2o, la));
+    return st.finish();
+}
+
+template <typename FT>
+static int rel_hum_t(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay, const void *t_lay,
+                     const rrtmgp_params *ps, const void *vmr_h2o) {
+    const size_t n = (size_t)ws->ncol * ws->nlay * sizeof(FT);
+    Stager st{ws, {}};
+    const FT *pl, *tl, *h2o;
+    FT *r;
+    TRY(st.in(mem, S_PLAY, p_lay, n, (const void **)&pl));
+    TRY(st.in(mem, S_TLAY, t_lay, n, (const void **)&tl));
+    TRY(st.in(mem, S_VMR_H2O, vmr_h2o, n, (const void **)&h2o));
+    TRY(st.out(mem, S_AUX0, rh, n, (void **)&r));
+    TRY(launch_rel_hum<FT>(ws, (int)ws->ncol, (int)ws->nlay, r, pl, tl, *ps, h2o));
+    return st.finish();
+}
+
+}  // namespace rrtmgp
+
+using namespace rrtmgp;
+
+// ======================================================================================
+extern "C" {
+
+int rrtmgp_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return set_error(RRTMGP_ENODEV, "no HIP device visible");
+    return n;
+}
+
+int rrtmgp_hip_gas_lookup_create(const rrtmgp_gas_lookup_desc *desc, int device, rrtmgp_lookup **out) {
+    RR_CHECK(desc && out, "null argument");
+    RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
+    TRY(select_device(device));
+    auto *lk = new rrtmgp_lookup();
+    lk->kind = LK_GAS; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    int rc = desc->ftype == RRTMGP_F32 ? build_gas<float>(lk, desc, lk->gas32) : build_gas<double>(lk, desc, lk->gas64);
+    if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
+    *out = lk;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_cloud_lookup_create(const rrtmgp_cloud_lookup_desc *desc, int device, rrtmgp_lookup **out) {
+    RR_CHECK(desc && out, "null argument");
+    RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
+    TRY(select_device(device));
+    auto *lk = new rrtmgp_lookup();
+    lk->kind = LK_CLOUD; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    int rc = desc->ftype == RRTMGP_F32 ? build_cld<float>(lk, desc, lk->cld32) : build_cld<double>(lk, desc, lk->cld64);
+    if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
+    *out = lk;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_aerosol_lookup_create(const rrtmgp_aerosol_lookup_desc *desc, int device, rrtmgp_lookup **out) {
+    RR_CHECK(desc && out, "null argument");
+    RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
+    TRY(select_device(device));
+    auto *lk = new rrtmgp_lookup();
+    lk->kind = LK_AEROSOL; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    int rc = desc->ftype == RRTMGP_F32 ? build_aero<float>(lk, desc, lk->aero32) : build_aero<double>(lk, desc, lk->aero64);
+    if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
+    *out = lk;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_lookup_destroy(rrtmgp_lookup *lk) {
+    if (!lk) return RRTMGP_OK;
+    (void)hipSetDevice(lk->device);
+    for (void *p : lk->allocs) (void)hipFree(p);
+    delete lk;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_workspace_create(int device, int64_t ncol, int64_t nlay, int32_t ftype, rrtmgp_workspace **out) {
+    RR_CHECK(out, "null argument");
+    RR_CHECK(ftype == RRTMGP_F32 || ftype == RRTMGP_F64, "ftype must be 4 or 8");
+    RR_CHECK(ncol >= 1 && nlay >= 2 && ncol < (1LL << 31) && nlay < 4096, "bad workspace dimensions");
+    TRY(select_device(device));
+    auto *ws = new rrtmgp_workspace();
+    ws->device = device; ws->ftype = ftype; ws->ncol = ncol; ws->nlay = nlay;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ws; return set_error(RRTMGP_EHIP, "hipGetDeviceProperties failed"); }
+    ws->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ws->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ws->ev_start) != hipSuccess || hipEventCreate(&ws->ev_stop) != hipSuccess) {
+        delete ws;
+        return set_error(RRTMGP_EHIP, "stream / event creation failed");
+    }
+    ws->stream = ws->own_stream;
+    ws->timed = true;
+    ws->stage.resize(S_NSLOTS);
+    *out = ws;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
+    if (!ws) return RRTMGP_OK;
+    (void)hipSetDevice(ws->device);
+    (void)hipStreamSynchronize(ws->stream);
+    for (auto &b : ws->stage) if (b.ptr) (void)hipFree(b.ptr);
+    if (ws->scratch.ptr) (void)hipFree(ws->scratch.ptr);
+    if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);
+    if (ws->ev_stop) (void)hipEventDestroy(ws->ev_stop);
+    if (ws->own_stream) (void)hipStreamDestroy(ws->own_stream);
+    delete ws;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream) {
+    RR_CHECK(ws, "null workspace");
+    ws->stream = hip_stream ? (hipStream_t)hip_stream : ws->own_stream;
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws) {
+    RR_CHECK(ws, "null workspace");
+    RR_HIP(hipSetDevice(ws->device));
+    RR_HIP(hipStreamSynchronize(ws->stream));
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms) {
+    RR_CHECK(ws && ms, "null argument");
+    RR_HIP(hipSetDevice(ws->device));
+    RR_HIP(hipEventSynchronize(ws->ev_stop));
+    float f = 0;
+    RR_HIP(hipEventElapsedTime(&f, ws->ev_start, ws->ev_stop));
+    *ms = f;
+    return RRTMGP_OK;
+}
+
+#define GAS_DISPATCH(ws, fn, lk, cld, aero, ...)                                                                      \
+    ((ws)->ftype == RRTMGP_F32                                                                                        \
+         ? fn<float>(ws, twostream, (lk)->gas32, (cld) ? &(cld)->cld32 : nullptr, (aero) ? &(aero)->aero32 : nullptr, \
+                     (lk)->max_minor, __VA_ARGS__)                                                                    \
+         : fn<double>(ws, twostream, (lk)->gas64, (cld) ? &(cld)->cld64 : nullptr, (aero) ? &(aero)->aero64 : nullptr, \
+                      (lk)->max_minor, __VA_ARGS__))
+
+int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
+                                    const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
+    const int twostream = 1;
+    return GAS_DISPATCH(ws, solve_lw_t, lookup_lw, cld, aero, as, bcs, flux, opts);
+}
+
+int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
+                                   const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                                   const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
+    const int twostream = 0;
+    return GAS_DISPATCH(ws, solve_lw_t, lookup_lw, cld, aero, as, bcs, flux, opts);
+}
+
+int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_lookup *cld,
+                                    const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
+                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_common(ws, lookup_sw, 1, cld, aero, as));
+    const int twostream = 1;
+    return GAS_DISPATCH(ws, solve_sw_t, lookup_sw, cld, aero, as, bcs, flux, opts);
+}
+
+int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_atmos_state *as,
+                                   const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_common(ws, lookup_sw, 1, nullptr, nullptr, as));
+    const int twostream = 0;
+    const rrtmgp_lookup *cld = nullptr, *aero = nullptr;
+    return GAS_DISPATCH(ws, solve_sw_t, lookup_sw, cld, aero, as, bcs, flux, opts);
+}
+
+static int check_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const void *bcs, const rrtmgp_flux_out *flux) {
+    RR_CHECK(ws && gs && bcs && flux, "null argument");
+    RR_CHECK(gs->ncol == ws->ncol && gs->nlay == ws->nlay, "state dimensions differ from the workspace");
+    RR_CHECK(gs->otp_kind == 0 || gs->otp_kind == 1, "unknown gray optical-thickness kind");
+    RR_CHECK(gs->p_lay && gs->p_lev, "gray state: missing pressure arrays");
+    RR_HIP(hipSetDevice(ws->device));
+    return RRTMGP_OK;
+}
+
+int rrtmgp_hip_rte_lw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_lw_bcs *bcs,
+                                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_gray(ws, as, bcs, flux));
+    RR_CHECK(as->lat && as->t_lay && as->t_lev && as->t_sfc && bcs->sfc_emis, "gray LW: missing array");
+    return ws->ftype == RRTMGP_F32 ? solve_gray_lw_t<float>(ws, 1, as, bcs, flux, opts)
+                                   : solve_gray_lw_t<double>(ws, 1, as, bcs, flux, opts);
+}
+int rrtmgp_hip_rte_lw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_lw_bcs *bcs,
+                                        const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_gray(ws, as, bcs, flux));
+    RR_CHECK(as->lat && as->t_lay && as->t_lev && as->t_sfc && bcs->sfc_emis, "gray LW: missing array");
+    RR_CHECK(!opts || opts->n_gauss_angles <= 1, "gray radiation is solved with a single quadrature angle");
+    return ws->ftype == RRTMGP_F32 ? solve_gray_lw_t<float>(ws, 0, as, bcs, flux, opts)
+                                   : solve_gray_lw_t<double>(ws, 0, as, bcs, flux, opts);
+}
+int rrtmgp_hip_rte_sw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_sw_bcs *bcs,
+                                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_gray(ws, as, bcs, flux));
+    RR_CHECK(bcs->cos_zenith && bcs->toa_flux && bcs->sfc_alb_direct && bcs->sfc_alb_diffuse && flux->flux_dn_dir,
+             "gray SW: missing array");
+    return ws->ftype == RRTMGP_F32 ? solve_gray_sw_t<float>(ws, 1, as, bcs, flux, opts)
+                                   : solve_gray_sw_t<double>(ws, 1, as, bcs, flux, opts);
+}
+int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_sw_bcs *bcs,
+                                        const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(check_gray(ws, as, bcs, flux));
+    RR_CHECK(bcs->cos_zenith && bcs->toa_flux && flux->flux_dn_dir, "gray SW: missing array");
+    return ws->ftype == RRTMGP_F32 ? solve_gray_sw_t<float>(ws, 0, as, bcs, flux, opts)
+                                   : solve_gray_sw_t<double>(ws, 0, as, bcs, flux, opts);
+}
+
+int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry,
+                               const rrtmgp_params *params, const void *vmr_h2o, const void *lat) {
+    RR_CHECK(ws && p_lev && col_dry && params, "null argument");
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? col_gas_t<float>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat)
+                                   : col_gas_t<double>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat);
+}
+
+int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
+                                         const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o) {
+    RR_CHECK(ws && rh && p_lay && t_lay && params && vmr_h2o, "null argument");
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? rel_hum_t<float>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o)
+                                   : rel_hum_t<double>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o);
+}
+
+double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32_t is_sw, int32_t draw) {
+    return mcica_draw(mcica_key(seed, gcol, igpt, is_sw), draw);
+}
+
+int rrtmgp_hip_last_error(char *buf, size_t n) {
+    if (!buf || n == 0) return RRTMGP_EINVAL;
+    snprintf(buf, n, "%s", g_last_error.c_str());
+    return RRTMGP_OK;
+}
+
+const char *rrtmgp_hip_version(void) { return "0.1.0"; }
+
+/* sizes of the ABI structs as compiled, for binding self-checks (tests/test_abi.py) */
+int rrtmgp_hip_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(rrtmgp_minor_desc);
+        case 1: return (int)sizeof(rrtmgp_gas_lookup_desc);
+        case 2: return (int)sizeof(rrtmgp_cloud_lookup_desc);
+        case 3: return (int)sizeof(rrtmgp_aerosol_lookup_desc);
+        case 4: return (int)sizeof(rrtmgp_atmos_state);
+        case 5: return (int)sizeof(rrtmgp_lw_bcs);
+        case 6: return (int)sizeof(rrtmgp_sw_bcs);
+        case 7: return (int)sizeof(rrtmgp_flux_out);
+        case 8: return (int)sizeof(rrtmgp_solve_opts);
+        case 9: return (int)sizeof(rrtmgp_gray_state);
+        case 10: return (int)sizeof(rrtmgp_params);
+        default: return -1;
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+// common.h — device-side table/state views and host-side handles of libhip_rrtmgp.so.
+//
+// gfx950 (MI355X) only.  Tables are re-laid-out g-point-innermost at lookup
+// creation so that the 64 lanes of a wavefront (= 64 consecutive g-points of one
+// column) read each interpolation corner as one coalesced 256-byte segment.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmgp_hip.h"
+
+namespace rrtmgp {
+
+// ---- device views (trivially copyable; passed to kernels by value) -------------
+
+// LookUpLW / LookUpSW (src/optics/LookUpTables.jl:130-201), device layout.
+template <typename FT>
+struct DevGas {
+    int is_sw, n_gpt, n_bnd, n_eta, n_pp /* n_p_ref + 1 */, n_t_ref, n_gases, n_t_plnk, idx_h2o;
+    FT p_ref_tropo;
+    const FT *kmajor;      // [t][p][eta][gpt]
+    const FT *pfrac;       // [t][p][eta][gpt]            (LW)
+    const FT *t_planck;    // [n_t_plnk]                  (LW)
+    const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
+    const FT *ln_p_ref;    // [n_p_ref]
+    const FT *t_ref;       // [n_t_ref]
+    const FT *vmr_ref;     // (2, n_gases, n_t_ref) as the reference stores it
+    const int *key_species;  // (2, 2, n_bnd), gas indices as in the reference
+    const int *gpt2bnd;      // [n_gpt] 0-based band
+    const int *bnd_lo;       // [n_bnd] first g-point (0-based) of the band
+    const int *bnd_ng;       // [n_bnd] g-points in the band
+    // minor gases, region 0 = lower, 1 = upper atmosphere
+    const int *m_bnd_st[2];   // [n_bnd+1] 0-based start into gasdata columns
+    const int *m_gasdata[2];  // (4, n_min_absrb)
+    const int *m_koff[2];     // [n_bnd] offset of the band's block along the contributor axis
+    const FT *m_kminor[2];    // [t][eta][contrib], contrib = koff[b] + i*ng_b + (g - lo_b)
+    int m_ncontrib[2];
+    const FT *rayl[2];           // [t][eta][gpt]   (SW)
+    const FT *solar_src_scaled;  // [n_gpt]         (SW)
+};
+
+// LookUpCld (LookUpTables.jl:239-284); data kept in the reference layout.
+template <typename FT>
+struct DevCld {
+    int nband, nrghice, nsize_liq, nsize_ice;
+    FT radliq_lwr, radliq_upr, radice_lwr, radice_upr;
+    const FT *liqdata;  // (3*nsize_liq, nband)
+    const FT *icedata;  // (3*nsize_ice, nband, nrghice)
+};
+
+// LookUpAerosolMerra (LookUpTables.jl:312-325); reference layouts.
+template <typename FT>
+struct DevAero {
+    int nband, nbin, nrh, iband_550nm;
+    const FT *size_bin_limits, *rh_levels, *dust, *sea_salt, *sulfate, *black_carbon_rh, *black_carbon,
+        *organic_carbon_rh, *organic_carbon;
+};
+
+// AtmosphericState (+ cloud / aerosol state) device view, reference layouts.
+template <typename FT>
+struct DevState {
+    int ncol, nlay, ngas, vmr_kind;
+    const FT *layerdata, *t_lev, *t_sfc;
+    const FT *vmr_h2o, *vmr_o3, *vmr;
+    const FT *cld_r_eff_liq, *cld_r_eff_ice, *cld_path_liq, *cld_path_ice, *cld_frac;
+    FT *cld_cover;  // LW or SW cover for this solve, or nullptr
+    int ice_rgh;
+    const FT *aero_size, *aero_mass;
+    FT *aod_sw_ext, *aod_sw_sca;
+};
+
+template <typename FT>
+struct DevFlux {
+    FT *up, *dn, *net, *dir;
+    int layout;
+    const FT *metric;  // (nlev, ncol) or nullptr
+};
+
+// ---- host-side handles ------------------------------------------------------------
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+enum LookupKind { LK_GAS = 1, LK_CLOUD = 2, LK_AEROSOL = 3 };
+
+}  // namespace rrtmgp
+
+struct rrtmgp_lookup {
+    int kind;
+    int ftype;
+    int device;
+    std::vector<void *> allocs;  // every device allocation owned by this lookup
+    // one of the following is valid, by (kind, ftype)
+    rrtmgp::DevGas<float> gas32;
+    rrtmgp::DevGas<double> gas64;
+    rrtmgp::DevCld<float> cld32;
+    rrtmgp::DevCld<double> cld64;
+    rrtmgp::DevAero<float> aero32;
+    rrtmgp::DevAero<double> aero64;
+    int max_minor;  // largest per-band minor count (either region)
+};
+
+struct rrtmgp_workspace {
+    int device;
+    int ftype;
+    int64_t ncol, nlay;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    int n_cu = 0;
+    // staging mirrors for host-memory callers, keyed by slot
+    std::vector<rrtmgp::DeviceBuffer> stage;
+    // per-(block, level, lane) scratch of the vertical sweeps
+    rrtmgp::DeviceBuffer scratch;
+};
+
+namespace rrtmgp {
+
+int set_error(int code, const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define RR_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return rrtmgp::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define RR_CHECK(cond, msg)                                         \
+    do {                                                            \
+        if (!(cond)) return rrtmgp::set_error(RRTMGP_EINVAL, msg);  \
+    } while (0)
+
+// ensure ws->stage[slot] holds at least `bytes`
+int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes);
+int scratch_ensure(rrtmgp_workspace *ws, size_t bytes);
+
+// Launchers implemented in the .hip translation units.  `which`: 1 = two-stream, 0 = no-scattering.
+template <typename FT>
+int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl, int n_angles,
+              uint64_t seed, int64_t col_offset, int max_minor);
+template <typename FT>
+int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+              const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
+              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_minor);
+
+struct GrayArgs {
+    int otp_kind;
+    double otp[5];
+    double stefan;
+};
+template <typename FT>
+int launch_gray_lw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, const GrayArgs &ga, const FT *lat,
+                   const FT *p_lay, const FT *p_lev, const FT *t_lay, const FT *t_lev, const FT *t_sfc,
+                   const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl);
+template <typename FT>
+int launch_gray_sw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, const GrayArgs &ga, const FT *p_lay,
+                   const FT *p_lev, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
+                   const DevFlux<FT> &fl);
+template <typename FT>
+int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, const FT *p_lev, FT *col_dry, const rrtmgp_params &ps,
+                   const FT *vmr_h2o, const FT *lat);
+template <typename FT>
+int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p_lay, const FT *t_lay,
+                   const rrtmgp_params &ps, const FT *vmr_h2o);
+
+}  // namespace rrtmgp

@@ -1,0 +1,310 @@
+// solve_lw.hip — longwave column kernels (two-stream and no-scattering) for gfx950.
+//
+// Replaces rte_lw_2stream_solve! / rte_lw_noscat_solve! of the reference
+// (ext/cuda/rte_longwave_2stream.jl:48-141, rte_longwave_noscat.jl:54-150; bodies
+// src/rte/longwave_2stream.jl, longwave_noscat.jl, src/optics/compute_optical_props.jl:18-245).
+//
+// One workgroup per column, one lane per g-point.  Two-stream: a single
+// bottom-up sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
+// reflectance/transmittance and the adding step, and leaves 4 numbers per level
+// (A, B, albedo, src) so that the top-down sweep is two FMAs per level:
+//     F_k = A_k F_{k+1} + B_k ,   U_k = albedo_k F_k + src_k .
+// Broadband fluxes are wavefront sums over g-points (fixed butterfly order).
+#include "device.h"
+
+namespace rrtmgp {
+
+// lw_2stream_coeffs, src/rte/longwave_2stream.jl:149-222
+template <typename FT>
+__device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_src_bot, FT lev_src_top, FT &Rdif,
+                                                  FT &Tdif, FT &src_up, FT &src_dn) {
+    const FT lw_diff_sec = FT(1.66);
+    const FT gamma1 = lw_diff_sec * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
+    const FT gamma2 = lw_diff_sec * FT(0.5) * ssa * (FT(1) - g);
+    const FT k = m_sqrt(m_max(lw_diff_sec * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
+    const FT e1 = m_exp(-tau * k);
+    const FT om1 = -m_expm1(-tau * k);
+    const FT coeff = e1 * e1;
+    const FT one_minus_e2kt = om1 * (FT(1) + e1);
+    const FT RT_term = FT(1) / (k * (FT(1) + coeff) + gamma1 * one_minus_e2kt);
+    Rdif = RT_term * gamma2 * one_minus_e2kt;
+    Tdif = RT_term * FT(2) * k * e1;
+    if (tau > FT(0)) {
+        const FT dB = lev_src_bot - lev_src_top;
+        const FT gamma_sum = gamma1 + gamma2;
+        const FT one_p_e1 = FT(1) + e1;
+        const FT emis_fac = om1 * (k * om1 + lw_diff_sec * (FT(1) - ssa) * one_p_e1) * RT_term;
+        const FT dBz = dB * (om1 / tau) * (k * om1 + gamma_sum * one_p_e1) * RT_term / m_max(gamma_sum, Num<FT>::eps());
+        src_up = Num<FT>::pi() * (lev_src_top * emis_fac - Tdif * dB + dBz);
+        src_dn = Num<FT>::pi() * (lev_src_bot * emis_fac + Tdif * dB - dBz);
+    } else {
+        src_up = FT(0);
+        src_dn = FT(0);
+    }
+}
+
+// Planck band source at a tabulated position: interp1d_equispaced(T, t_planck, totplnk)
+template <typename FT>
+__device__ __forceinline__ FT planck_at(const FT *totplnk_band, int loc, FT f) {
+    return totplnk_band[loc] * (FT(1) - f) + totplnk_band[loc + 1] * f;
+}
+
+template <typename FT>
+struct LwArgs {
+    DevGas<FT> lk;
+    DevCld<FT> cld;
+    DevAero<FT> aero;
+    DevState<FT> as;
+    DevFlux<FT> fl;
+    const FT *sfc_emis;  // (nbnd, ncol)
+    const FT *inc_flux;  // (ncol, ngpt) or nullptr
+    FT *scratch;
+    ColDims dims;
+    int n_angles;
+    FT Ds[4], wts[4];
+    uint64_t seed;
+    int64_t col_offset;
+};
+
+// optics of one layer for this lane: gas + cloud + aerosol increments (TwoStream) or absorption only (OneScalar)
+template <typename FT, bool TWOSTREAM>
+__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
+                                                uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
+    const int nlay = a.dims.nlay;
+    gas_optics<FT, false>(a.lk, sh, lb, k, nlay, tau, ssa, pfrac);
+    g = FT(0);
+    if (a.dims.has_cld && mask_bit(m0, m1, k)) {
+        if (TWOSTREAM) add_cloud_2stream(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, false, tau, ssa, g);
+        else add_cloud_1scalar(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, tau);
+    }
+    if (a.dims.has_aero && sh.aero_mask[k]) {
+        if (TWOSTREAM) {
+            FT e = FT(0), s = FT(0);
+            add_aerosol_2stream(a.aero, sh, lb.ibnd, k, nlay, false, tau, ssa, g, e, s);
+        } else {
+            FT ta, tsa, tsga;
+            lookup_aerosol(a.aero, sh, lb.ibnd, k, nlay, ta, tsa, tsga);
+            tau += (ta - tsa);  // aerosol_optics.jl:45
+        }
+    }
+}
+
+template <typename FT, bool TWOSTREAM>
+__global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
+    extern __shared__ __align__(16) char smem[];
+    ColShared<FT> sh;
+    carve_shared(sh, smem, a.dims);
+    const ColDims &d = a.dims;
+    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool active = tid < a.lk.n_gpt;
+    const int g = active ? tid : a.lk.n_gpt - 1;
+    const LaneBand lb = lane_band(a.lk, g);
+    const FT *totplnk = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd;
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x, (int)blockDim.x};
+    const FT amask = active ? FT(1) : FT(0);
+
+    for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
+        prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
+
+        uint64_t m0 = 0, m1 = 0;
+        bool cloudy = false;
+        if (d.has_cld) {
+            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 0);
+            cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
+            const unsigned long long b = __ballot(cloudy);
+            if (lane == 0) sh.misc[wave] = __popcll(b);
+        }
+        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
+        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)ncol * g] : FT(0);
+        FT *acc = sh.acc + (size_t)wave * nlev * d.n_acc;
+
+        if (TWOSTREAM) {
+            // ---- bottom-up: optics + sources + coefficients + adding (longwave_2stream.jl:273-302) ----
+            FT tau, ssa, gg, pfrac;
+            lw_layer_optics<FT, true>(a, sh, lb, 0, m0, m1, tau, ssa, gg, pfrac);
+            const FT sfc_source = planck_at(totplnk, sh.misc[d.nwaves], sh.miscf[0]) * pfrac;
+            FT B_lev = planck_at(totplnk, sh.pl_lev_loc[1], sh.pl_lev_f[1]);             // B(t_lev[k+1])
+            FT lev_src_bot = planck_at(totplnk, sh.pl_lev_loc[0], sh.pl_lev_f[0]) * pfrac;  // lev_source[1]
+            FT lev_src_inc_prev = B_lev * pfrac;
+            FT albedo = FT(1) - emis;
+            FT src = Num<FT>::pi() * emis * sfc_source;
+            for (int k = 0; k < nlay; k++) {
+                FT tau_n = FT(0), ssa_n = FT(0), g_n = FT(0), lev_src_top, inc_next = FT(0);
+                if (k + 1 < nlay) {
+                    FT pfrac_n;
+                    lw_layer_optics<FT, true>(a, sh, lb, k + 1, m0, m1, tau_n, ssa_n, g_n, pfrac_n);
+                    const FT lev_src_dec = B_lev * pfrac_n;
+                    lev_src_top = m_sqrt(lev_src_inc_prev * lev_src_dec);  // compute_optical_props.jl:189
+                    B_lev = planck_at(totplnk, sh.pl_lev_loc[k + 2], sh.pl_lev_f[k + 2]);
+                    inc_next = B_lev * pfrac_n;
+                } else {
+                    lev_src_top = lev_src_inc_prev;
+                }
+                FT Rdif, Tdif, src_up, src_dn;
+                lw_2stream_coeffs(tau, ssa, gg, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
+                const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
+                sw.at(k, 0) = Tdif * denom;                          // A_k
+                sw.at(k, 1) = (Rdif * src + src_dn) * denom;         // B_k
+                sw.at(k, 2) = albedo;
+                sw.at(k, 3) = src;
+                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;               // Eq 9
+                src = src_up + Tdif * denom * (src + albedo * src_dn);                 // Eq 11
+                albedo = albedo_n;
+                lev_src_bot = lev_src_top;
+                lev_src_inc_prev = inc_next;
+                tau = tau_n; ssa = ssa_n; gg = g_n;
+            }
+            // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
+            FT F = inc;
+            {
+                const FT up = (F * albedo + src) * amask, dn = F * amask;
+                const FT su = wave_sum(up), sd = wave_sum(dn);
+                if (lane == 0) { acc[(size_t)nlay * 2] = su; acc[(size_t)nlay * 2 + 1] = sd; }
+            }
+            for (int k = nlay - 1; k >= 0; k--) {
+                F = sw.at(k, 0) * F + sw.at(k, 1);
+                const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
+                const FT su = wave_sum(up), sd = wave_sum(F * amask);
+                if (lane == 0) { acc[(size_t)k * 2] = su; acc[(size_t)k * 2 + 1] = sd; }
+            }
+        } else {
+            // ---- no-scattering: optics sweep, then one down + one up transport per angle
+            //      (longwave_noscat.jl:45-96, 224-301) ----
+            FT sfc_source = FT(0);
+            {
+                FT lev_src_inc_prev = FT(0);
+                FT B_lev = planck_at(totplnk, sh.pl_lev_loc[0], sh.pl_lev_f[0]);
+                for (int k = 0; k < nlay; k++) {
+                    FT tau, ssa, gg, pfrac;
+                    lw_layer_optics<FT, false>(a, sh, lb, k, m0, m1, tau, ssa, gg, pfrac);
+                    const FT lev_src_dec = B_lev * pfrac;
+                    B_lev = planck_at(totplnk, sh.pl_lev_loc[k + 1], sh.pl_lev_f[k + 1]);
+                    const FT lev_src_inc = B_lev * pfrac;
+                    const FT lay_src = planck_at(totplnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]) * pfrac;
+                    FT lev_src;
+                    if (k == 0) {
+                        sfc_source = planck_at(totplnk, sh.misc[d.nwaves], sh.miscf[0]) * pfrac;
+                        lev_src = lev_src_dec;
+                    } else {
+                        lev_src = m_sqrt(lev_src_inc_prev * lev_src_dec);
+                    }
+                    sw.at(k, 0) = tau;
+                    sw.at(k, 1) = lay_src;
+                    sw.at(k, 2) = lev_src;
+                    lev_src_inc_prev = lev_src_inc;
+                }
+                sw.at(nlay, 2) = lev_src_inc_prev;
+            }
+            const FT tthresh = tau_thresh<FT>();
+            for (int imu = 0; imu < a.n_angles; imu++) {
+                const FT Ds = a.Ds[imu], w_mu = a.wts[imu];
+                const FT i2f = Num<FT>::pi() * w_mu;
+                FT I = a.inc_flux ? inc / Num<FT>::pi() : FT(0);
+                const bool first = imu == 0;
+                {
+                    const FT sd = wave_sum(I * i2f * amask);
+                    if (lane == 0) acc[(size_t)nlay * 2 + 1] = first ? sd : acc[(size_t)nlay * 2 + 1] + sd;
+                }
+                for (int k = nlay - 1; k >= 0; k--) {
+                    const FT tau_loc = sw.at(k, 0) * Ds;
+                    const FT trans = m_exp(-tau_loc);
+                    const FT lay_src = sw.at(k, 1), lev_src = sw.at(k, 2);
+                    const FT fact = (tau_loc > tthresh)
+                                        ? ((FT(1) - trans) / tau_loc - trans)
+                                        : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
+                    I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
+                    const FT sd = wave_sum(I * i2f * amask);
+                    if (lane == 0) acc[(size_t)k * 2 + 1] = first ? sd : acc[(size_t)k * 2 + 1] + sd;
+                }
+                I = I * (FT(1) - emis) + emis * sfc_source;
+                {
+                    const FT su = wave_sum(I * i2f * amask);
+                    if (lane == 0) acc[0] = first ? su : acc[0] + su;
+                }
+                for (int lev = 1; lev <= nlay; lev++) {
+                    const FT tau_loc = sw.at(lev - 1, 0) * Ds;
+                    const FT trans = m_exp(-tau_loc);
+                    const FT lay_src = sw.at(lev - 1, 1), lev_src = sw.at(lev, 2);
+                    const FT fact = (tau_loc > tthresh)
+                                        ? ((FT(1) - trans) / tau_loc - trans)
+                                        : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
+                    I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
+                    const FT su = wave_sum(I * i2f * amask);
+                    if (lane == 0) acc[(size_t)lev * 2] = first ? su : acc[(size_t)lev * 2] + su;
+                }
+            }
+        }
+        __syncthreads();
+        store_column(a.fl, sh, d, col, ncol, false);
+        if (d.has_cld && a.as.cld_cover && tid == 0) {
+            int n = 0;
+            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+            a.as.cld_cover[col] = FT(n) / FT(a.lk.n_gpt);
+        }
+        __syncthreads();
+    }
+}
+
+// Gauss-Jacobi-5 secants and weights, src/optics/AngularDiscretizations.jl:41-56
+static void angular_discretization(int n, double *Ds, double *wts) {
+    static const double mu[4][4] = {{0.6096748751, 0, 0, 0},
+                                    {0.2509907356, 0.7908473988, 0, 0},
+                                    {0.1024922169, 0.4417960320, 0.8633751621, 0},
+                                    {0.0454586727, 0.2322334416, 0.5740198775, 0.9030775973}};
+    static const double w[4][4] = {{1, 0, 0, 0},
+                                   {0.2300253764, 0.7699746236, 0, 0},
+                                   {0.0437820218, 0.3875796738, 0.5686383044, 0},
+                                   {0.0092068785, 0.1285704278, 0.4323381850, 0.4298845087}};
+    for (int i = 0; i < n; i++) { Ds[i] = 1.0 / mu[n - 1][i]; wts[i] = w[n - 1][i]; }
+}
+
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
+
+template <typename FT>
+int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl, int n_angles,
+              uint64_t seed, int64_t col_offset, int max_minor) {
+    (void)max_minor;
+    LwArgs<FT> a{};
+    a.lk = lk;
+    if (cld) a.cld = *cld;
+    if (aero) a.aero = *aero;
+    a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux;
+    a.seed = seed; a.col_offset = col_offset;
+    const int threads = ((lk.n_gpt + 63) / 64) * 64;
+    RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
+    ColDims d{};
+    d.nlay = as.nlay; d.nlev = as.nlay + 1;
+    d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
+    d.nwaves = threads / 64; d.lw = 1; d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 2;
+    RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
+    a.dims = d;
+    a.n_angles = twostream ? 1 : n_angles;
+    double Ds[4], wts[4];
+    angular_discretization(a.n_angles, Ds, wts);
+    for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
+    ColShared<FT> dummy;
+    const size_t lds = carve_shared(dummy, (char *)nullptr, d);
+    const int grid = column_grid(ws, as.ncol, threads, lds);
+    if (grid < 0) return grid;
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 4 * threads * sizeof(FT));
+    if (rc) return rc;
+    a.scratch = (FT *)ws->scratch.ptr;
+    auto kern = twostream ? lw_solve_kernel<FT, true> : lw_solve_kernel<FT, false>;
+    RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
+    RR_HIP(hipGetLastError());
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_stop, ws->stream));
+    return RRTMGP_OK;
+}
+
+template int launch_lw<float>(rrtmgp_workspace *, int, const DevGas<float> &, const DevCld<float> *,
+                              const DevAero<float> *, const DevState<float> &, const float *, const float *,
+                              const DevFlux<float> &, int, uint64_t, int64_t, int);
+template int launch_lw<double>(rrtmgp_workspace *, int, const DevGas<double> &, const DevCld<double> *,
+                               const DevAero<double> *, const DevState<double> &, const double *, const double *,
+                               const DevFlux<double> &, int, uint64_t, int64_t, int);
+
+}  // namespace rrtmgp

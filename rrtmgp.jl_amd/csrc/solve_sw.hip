@@ -1,0 +1,255 @@
+// solve_sw.hip — shortwave column kernels (two-stream and no-scattering) for gfx950.
+//
+// Replaces rte_sw_2stream_solve! / rte_sw_noscat_solve! of the reference
+// (ext/cuda/rte_shortwave_2stream.jl:58-175, rte_shortwave_noscat.jl:54-112; bodies
+// src/rte/shortwave_2stream.jl, shortwave_noscat.jl, src/optics/compute_optical_props.jl:263-388).
+//
+// One workgroup per column, one lane per g-point.  Two-stream runs three sweeps:
+//   1. top-down: gas/cloud/aerosol optics, cumulative direct beam, layer
+//      coefficients -> (Rdif, Tdif, Rdir*dir, Tdir*dir) per layer in the scratch;
+//   2. bottom-up: adding -> (A, B, albedo, src) per level, in place;
+//   3. top-down: F_k = A_k F_{k+1} + B_k, U_k = albedo_k F_k + src_k.
+// Night columns (mu0 <= 0) skip the solve and are zeroed, but still produce the
+// cloud-cover and 550 nm AOD diagnostics as the reference does.
+#include "device.h"
+
+namespace rrtmgp {
+
+// sw_2stream_coeffs, src/rte/shortwave_2stream.jl:189-279
+template <typename FT>
+__device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, FT &Rdir, FT &Tdir, FT &Rdif, FT &Tdif) {
+    const FT gamma1 = (FT(8) - ssa * (FT(5) + FT(3) * g)) * FT(0.25);
+    const FT gamma2 = FT(3) * (ssa * (FT(1) - g)) * FT(0.25);
+    const FT gamma3 = (FT(2) - (FT(3) * mu0) * g) * FT(0.25);
+    const FT gamma4 = FT(1) - gamma3;
+    const FT alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+    const FT alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+    const FT k = m_sqrt(m_max(FT(2) * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
+    const FT exp_minusktau = m_exp(-tau * k);
+    const FT exp_minus2ktau = exp_minusktau * exp_minusktau;
+    const FT om1 = -m_expm1(-tau * k);
+    const FT one_minus_e2kt = om1 * (FT(1) + exp_minusktau);
+    FT RT_term = FT(1) / (k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
+    Rdif = RT_term * gamma2 * one_minus_e2kt;
+    Tdif = RT_term * FT(2) * k * exp_minusktau;
+    const FT T0 = m_exp(-tau / m_max(mu0, mu0_min<FT>()));
+    FT k_mu = k * mu0;
+    FT k_mu2 = k_mu * k_mu;
+    const FT diff = FT(1) - k_mu2;
+    if (m_abs(diff) < resonance_window<FT>()) {
+        k_mu2 = diff >= FT(0) ? FT(1) - resonance_window<FT>() : FT(1) + resonance_window<FT>();
+        k_mu = m_sqrt(k_mu2);
+    }
+    const FT k_gamma3 = k * gamma3;
+    const FT k_gamma4 = k * gamma4;
+    RT_term = ssa * RT_term / (FT(1) - k_mu2);
+    const FT Rdir_u = RT_term * ((FT(1) - k_mu) * (alpha2 + k_gamma3) -
+                                 (FT(1) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
+                                 FT(2) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * T0);
+    const FT Tdir_u = -RT_term * ((FT(1) + k_mu) * (alpha1 + k_gamma4) * T0 -
+                                  (FT(1) - k_mu) * (alpha1 - k_gamma4) * exp_minus2ktau * T0 -
+                                  FT(2) * (k_gamma4 + alpha1 * k_mu) * exp_minusktau);
+    Rdir = m_max(FT(0), Rdir_u);
+    Tdir = m_max(FT(0), Tdir_u);
+    const FT av_energy = m_max(FT(0), FT(1) - T0);
+    const FT tot_dir = Rdir + Tdir;
+    if (tot_dir > av_energy) {
+        const FT scale = av_energy / m_max(Num<FT>::eps(), tot_dir);
+        Rdir *= scale;
+        Tdir *= scale;
+    }
+}
+
+template <typename FT>
+struct SwArgs {
+    DevGas<FT> lk;
+    DevCld<FT> cld;
+    DevAero<FT> aero;
+    DevState<FT> as;
+    DevFlux<FT> fl;
+    const FT *cos_zenith, *toa_flux, *alb_dir, *alb_dif;
+    FT *scratch;
+    ColDims dims;
+    uint64_t seed;
+    int64_t col_offset;
+};
+
+template <typename FT, bool TWOSTREAM>
+__global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
+    extern __shared__ __align__(16) char smem[];
+    ColShared<FT> sh;
+    carve_shared(sh, smem, a.dims);
+    const ColDims &d = a.dims;
+    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool active = tid < a.lk.n_gpt;
+    const int g = active ? tid : a.lk.n_gpt - 1;
+    const LaneBand lb = lane_band(a.lk, g);
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x, (int)blockDim.x};
+    const FT amask = active ? FT(1) : FT(0);
+    const FT solar_frac = a.lk.solar_src_scaled[g];
+    // the 550 nm AOD is the value of the LAST g-point of that band (aerosol_optics.jl:96-116)
+    const bool aod_lane = d.has_aero && a.aero.iband_550nm > 0 && lb.ibnd == a.aero.iband_550nm - 1 &&
+                          lb.gi == lb.ngb - 1 && active;
+
+    for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
+        const FT mu0 = a.cos_zenith[col];
+        const bool day = mu0 > FT(0);
+        if (!TWOSTREAM && !day) {  // shortwave_noscat.jl:86-99: nothing runs for night columns
+            store_column(a.fl, sh, d, col, ncol, true);
+            continue;
+        }
+        prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
+        FT *acc = sh.acc + (size_t)wave * nlev * d.n_acc;
+
+        if (!TWOSTREAM) {
+            // rte_sw_noscat!, shortwave_noscat.jl:120-148 (multiplicative Beer-Lambert, flux_up = 0)
+            FT dir = a.toa_flux[col] * solar_frac * mu0;
+            {
+                const FT s = wave_sum(dir * amask);
+                if (lane == 0) { acc[(size_t)nlay * 3] = FT(0); acc[(size_t)nlay * 3 + 1] = s; acc[(size_t)nlay * 3 + 2] = s; }
+            }
+            for (int k = nlay - 1; k >= 0; k--) {
+                FT tau, ssa, pf;
+                gas_optics<FT, true>(a.lk, sh, lb, k, nlay, tau, ssa, pf);
+                dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
+                const FT s = wave_sum(dir * amask);
+                if (lane == 0) { acc[(size_t)k * 3] = FT(0); acc[(size_t)k * 3 + 1] = s; acc[(size_t)k * 3 + 2] = s; }
+            }
+            __syncthreads();
+            store_column(a.fl, sh, d, col, ncol, false);
+            __syncthreads();
+            continue;
+        }
+
+        uint64_t m0 = 0, m1 = 0;
+        if (d.has_cld) {
+            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 1);
+            const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
+            const unsigned long long b = __ballot(cloudy);
+            if (lane == 0) sh.misc[wave] = __popcll(b);
+        }
+        FT aod_ext = FT(0), aod_sca = FT(0);
+
+        if (day) {
+            // ---- sweep 1, top-down: optics, direct beam, layer coefficients ----
+            const FT dir_top = a.toa_flux[col] * solar_frac * mu0;
+            const FT inv_mu0 = FT(1) / m_max(mu0, mu0_min<FT>());
+            FT tau_cum = FT(0), dir_above = dir_top;
+            {
+                const FT s = wave_sum(dir_top * amask);
+                if (lane == 0) acc[(size_t)nlay * 3 + 2] = s;
+            }
+            for (int k = nlay - 1; k >= 0; k--) {
+                FT tau, ssa, pf, gg = FT(0);
+                gas_optics<FT, true>(a.lk, sh, lb, k, nlay, tau, ssa, pf);
+                if (d.has_cld && mask_bit(m0, m1, k)) add_cloud_2stream(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, true, tau, ssa, gg);
+                if (d.has_aero && sh.aero_mask[k]) add_aerosol_2stream(a.aero, sh, lb.ibnd, k, nlay, true, tau, ssa, gg, aod_ext, aod_sca);
+                tau_cum += tau;
+                const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
+                FT Rdir, Tdir, Rdif, Tdif;
+                sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
+                sw.at(k, 0) = Rdif;
+                sw.at(k, 1) = Tdif;
+                sw.at(k, 2) = Rdir * dir_above;  // src_up_ilev
+                sw.at(k, 3) = Tdir * dir_above;  // src_dn_ilev
+                const FT s = wave_sum(dir_k * amask);
+                if (lane == 0) acc[(size_t)k * 3 + 2] = s;
+                dir_above = dir_k;
+            }
+            const FT dir_sfc = dir_above;
+            // ---- sweep 2, bottom-up: adding (shortwave_2stream.jl:340-361) ----
+            FT albedo = a.alb_dif[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
+            FT src = dir_sfc * a.alb_dir[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
+            for (int k = 0; k < nlay; k++) {
+                const FT Rdif = sw.at(k, 0), Tdif = sw.at(k, 1), src_up = sw.at(k, 2), src_dn = sw.at(k, 3);
+                const FT denom = FT(1) / (FT(1) - Rdif * albedo);
+                sw.at(k, 0) = Tdif * denom;
+                sw.at(k, 1) = (Rdif * src + src_dn) * denom;
+                sw.at(k, 2) = albedo;
+                sw.at(k, 3) = src;
+                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
+                src = src_up + Tdif * denom * (src + albedo * src_dn);
+                albedo = albedo_n;
+            }
+            // ---- sweep 3, top-down: fluxes (shortwave_2stream.jl:363-390); diffuse TOA incident = 0 ----
+            FT F = FT(0);
+            {
+                const FT su = wave_sum((F * albedo + src) * amask);
+                if (lane == 0) { acc[(size_t)nlay * 3] = su; acc[(size_t)nlay * 3 + 1] = acc[(size_t)nlay * 3 + 2]; }
+            }
+            for (int k = nlay - 1; k >= 0; k--) {
+                F = sw.at(k, 0) * F + sw.at(k, 1);
+                const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
+                const FT su = wave_sum(up), sd = wave_sum(F * amask);
+                if (lane == 0) { acc[(size_t)k * 3] = su; acc[(size_t)k * 3 + 1] = sd + acc[(size_t)k * 3 + 2]; }
+            }
+        } else if (d.has_aero && a.as.aod_sw_ext) {
+            // night column: the reference still runs the optics, so the AOD diagnostic is defined
+            for (int k = 0; k < nlay; k++) {
+                if (sh.aero_mask[k]) {
+                    FT ta, tsa, tsga;
+                    lookup_aerosol(a.aero, sh, lb.ibnd, k, nlay, ta, tsa, tsga);
+                    aod_ext += ta;
+                    aod_sca += tsa;
+                }
+            }
+        }
+        if (aod_lane && a.as.aod_sw_ext) { a.as.aod_sw_ext[col] = aod_ext; a.as.aod_sw_sca[col] = aod_sca; }
+        __syncthreads();
+        store_column(a.fl, sh, d, col, ncol, !day);
+        if (d.has_cld && a.as.cld_cover && tid == 0) {
+            int n = 0;
+            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+            a.as.cld_cover[col] = FT(n) / FT(a.lk.n_gpt);
+        }
+        __syncthreads();
+    }
+}
+
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
+
+template <typename FT>
+int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+              const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
+              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_minor) {
+    (void)max_minor;
+    SwArgs<FT> a{};
+    a.lk = lk;
+    if (cld) a.cld = *cld;
+    if (aero) a.aero = *aero;
+    a.as = as; a.fl = fl;
+    a.cos_zenith = cos_zenith; a.toa_flux = toa_flux; a.alb_dir = alb_dir; a.alb_dif = alb_dif;
+    a.seed = seed; a.col_offset = col_offset;
+    const int threads = ((lk.n_gpt + 63) / 64) * 64;
+    RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
+    ColDims d{};
+    d.nlay = as.nlay; d.nlev = as.nlay + 1;
+    d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
+    d.nwaves = threads / 64; d.lw = 0; d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3;
+    RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
+    a.dims = d;
+    ColShared<FT> dummy;
+    const size_t lds = carve_shared(dummy, (char *)nullptr, d);
+    const int grid = column_grid(ws, as.ncol, threads, lds);
+    if (grid < 0) return grid;
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 4 * threads * sizeof(FT));
+    if (rc) return rc;
+    a.scratch = (FT *)ws->scratch.ptr;
+    auto kern = twostream ? sw_solve_kernel<FT, true> : sw_solve_kernel<FT, false>;
+    RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
+    RR_HIP(hipGetLastError());
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_stop, ws->stream));
+    return RRTMGP_OK;
+}
+
+template int launch_sw<float>(rrtmgp_workspace *, int, const DevGas<float> &, const DevCld<float> *,
+                              const DevAero<float> *, const DevState<float> &, const float *, const float *,
+                              const float *, const float *, const DevFlux<float> &, uint64_t, int64_t, int);
+template int launch_sw<double>(rrtmgp_workspace *, int, const DevGas<double> &, const DevCld<double> *,
+                               const DevAero<double> *, const DevState<double> &, const double *, const double *,
+                               const double *, const double *, const DevFlux<double> &, uint64_t, int64_t, int);
+
+}  // namespace rrtmgp

@@ -1,0 +1,214 @@
+"""Layer-1 solver workspaces and `solve_lw` / `solve_sw`, bound to libhip_rrtmgp.so.
+
+Host-side mirror of the reference's `NoScatLWRTE`, `TwoStreamLWRTE`, `NoScatSWRTE`,
+`TwoStreamSWRTE` (src/rte/RTE.jl:53,111,177,229) and `solve_lw!` / `solve_sw!`
+(src/rte/RTESolver.jl:33-247): same argument order and meaning; the device dispatch
+on `context.device` becomes a call through the C ABI.  Julia's `solve_lw!` is
+`solve_lw` here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _abi, _lib
+from .lookups import GasLookup, LookUpAerosolMerra, LookUpCld
+from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, SwBCs, array_dtype, array_ptr,
+                     julia_shape)
+
+
+class DeviceLookup:
+    """A lookup table uploaded to HBM (handle owned by this object)."""
+
+    def __init__(self, host, device: int = 0):
+        self.host = host
+        self.device = device
+        self.handle = C.c_void_p()
+        d = host.desc()
+        L = _lib.lib()
+        if isinstance(host, GasLookup):
+            rc = L.rrtmgp_hip_gas_lookup_create(C.byref(d), device, C.byref(self.handle))
+        elif isinstance(host, LookUpCld):
+            rc = L.rrtmgp_hip_cloud_lookup_create(C.byref(d), device, C.byref(self.handle))
+        elif isinstance(host, LookUpAerosolMerra):
+            rc = L.rrtmgp_hip_aerosol_lookup_create(C.byref(d), device, C.byref(self.handle))
+        else:
+            raise TypeError(type(host))
+        _lib.check(rc, "lookup upload")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().rrtmgp_hip_lookup_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _dev(lk, device):
+    if lk is None:
+        return None
+    if isinstance(lk, DeviceLookup):
+        return lk
+    cache = getattr(lk, "_device_cache", None)
+    if cache is None:
+        cache = {}
+        object.__setattr__(lk, "_device_cache", cache)
+    if device not in cache:
+        cache[device] = DeviceLookup(lk, device)
+    return cache[device]
+
+
+class Workspace:
+    """Library-owned scratch for one (ncol, nlay, FT): what the reference keeps in
+    `op`, `src`, `fluxb`, `state_cache` and the masks (src/rte/RTE.jl)."""
+
+    def __init__(self, ncol: int, nlay: int, dtype, device: int = 0):
+        self.ncol, self.nlay, self.dtype, self.device = ncol, nlay, np.dtype(dtype), device
+        self.handle = C.c_void_p()
+        _lib.check(_lib.lib().rrtmgp_hip_workspace_create(device, ncol, nlay, _abi.ftype_of(dtype),
+                                                          C.byref(self.handle)), "workspace_create")
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        _lib.check(_lib.lib().rrtmgp_hip_workspace_set_stream(self.handle, C.c_void_p(stream_ptr or 0)), "set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        _lib.check(_lib.lib().rrtmgp_hip_workspace_synchronize(self.handle), "synchronize")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double()
+        _lib.check(_lib.lib().rrtmgp_hip_workspace_last_kernel_ms(self.handle, C.byref(ms)), "last_kernel_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().rrtmgp_hip_workspace_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _opts(n_gauss_angles, metric_scaling, seed, col_offset):
+    o = _abi.SolveOpts()
+    o.n_gauss_angles = n_gauss_angles
+    p, m = array_ptr(metric_scaling)
+    o.metric_scaling = p
+    o.metric_mem = m if m is not None else _abi.MEM_HOST
+    o.seed = seed
+    o.col_offset = col_offset
+    return o
+
+
+class _RTE:
+    """Common part of the four workspaces: boundary conditions, flux buffers, library scratch."""
+    twostream = True
+    sw = False
+
+    def __init__(self, ncol, nlay, dtype, bcs, device=0, flux_device=None, layout=_abi.LAYOUT_NLEV_NCOL,
+                 n_gauss_angles=1, workspace: Optional[Workspace] = None):
+        self.bcs = bcs
+        self.n_gauss_angles = n_gauss_angles
+        self.ws = workspace or Workspace(ncol, nlay, dtype, device)
+        self.flux = Flux.allocate(ncol, nlay + 1, dtype, sw=self.sw, layout=layout, device=flux_device)
+
+    @property
+    def device(self):
+        return self.ws.device
+
+
+class NoScatLWRTE(_RTE):
+    twostream, sw = False, False
+
+
+class TwoStreamLWRTE(_RTE):
+    twostream, sw = True, False
+
+
+class NoScatSWRTE(_RTE):
+    twostream, sw = False, True
+
+
+class TwoStreamSWRTE(_RTE):
+    twostream, sw = True, True
+
+
+def _null(h):
+    return None if h is None else h.handle
+
+
+def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=None, metric_scaling=None,
+             seed: int = 0, col_offset: int = 0) -> Flux:
+    """solve_lw! (RTESolver.jl:33,54,77,117).  Gray when `as_` is a GrayAtmosphericState."""
+    L = _lib.lib()
+    o = _opts(slv.n_gauss_angles, metric_scaling, seed, col_offset)
+    db, df = slv.bcs.desc(), slv.flux.desc()
+    if isinstance(as_, GrayAtmosphericState):
+        if slv.n_gauss_angles != 1:
+            raise ValueError("gray radiation is solved with a single quadrature angle")
+        dg = as_.desc()
+        fn = L.rrtmgp_hip_rte_lw_2stream_solve_gray if slv.twostream else L.rrtmgp_hip_rte_lw_noscat_solve_gray
+        _lib.check(fn(slv.ws.handle, C.byref(dg), C.byref(db), C.byref(df), C.byref(o)), "solve_lw (gray)")
+        return slv.flux
+    lw, cld, aero = _dev(lookup_lw, slv.device), _dev(lookup_lw_cld, slv.device), _dev(lookup_lw_aero, slv.device)
+    ds = as_.desc(cld is not None, aero is not None)
+    fn = L.rrtmgp_hip_rte_lw_2stream_solve if slv.twostream else L.rrtmgp_hip_rte_lw_noscat_solve
+    _lib.check(fn(slv.ws.handle, lw.handle, _null(cld), _null(aero), C.byref(ds), C.byref(db), C.byref(df), C.byref(o)),
+               "solve_lw")
+    return slv.flux
+
+
+def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=None, metric_scaling=None,
+             seed: int = 0, col_offset: int = 0) -> Flux:
+    """solve_sw! (RTESolver.jl:151,167,188,222)."""
+    L = _lib.lib()
+    o = _opts(1, metric_scaling, seed, col_offset)
+    db, df = slv.bcs.desc(), slv.flux.desc()
+    if isinstance(as_, GrayAtmosphericState):
+        dg = as_.desc()
+        fn = L.rrtmgp_hip_rte_sw_2stream_solve_gray if slv.twostream else L.rrtmgp_hip_rte_sw_noscat_solve_gray
+        _lib.check(fn(slv.ws.handle, C.byref(dg), C.byref(db), C.byref(df), C.byref(o)), "solve_sw (gray)")
+        return slv.flux
+    sw = _dev(lookup_sw, slv.device)
+    if slv.twostream:
+        cld, aero = _dev(lookup_sw_cld, slv.device), _dev(lookup_sw_aero, slv.device)
+        ds = as_.desc(cld is not None, aero is not None)
+        _lib.check(L.rrtmgp_hip_rte_sw_2stream_solve(slv.ws.handle, sw.handle, _null(cld), _null(aero), C.byref(ds),
+                                                     C.byref(db), C.byref(df), C.byref(o)), "solve_sw")
+    else:
+        if lookup_sw_cld is not None or lookup_sw_aero is not None:
+            raise ValueError("NoScatSWRTE takes no cloud / aerosol lookups (RTESolver.jl:188-209)")
+        ds = as_.desc(False, False)
+        _lib.check(L.rrtmgp_hip_rte_sw_noscat_solve(slv.ws.handle, sw.handle, C.byref(ds), C.byref(db), C.byref(df),
+                                                    C.byref(o)), "solve_sw")
+    return slv.flux
+
+
+def compute_col_gas(ws: Workspace, p_lev, params, vmr_h2o=None, lat=None, out=None):
+    """compute_col_gas! (src/optics/column_amounts.jl:14-43) on the device."""
+    nlev, ncol = julia_shape(p_lev)
+    if out is None:
+        out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
+    p, mem = array_ptr(p_lev)
+    pd = params.desc()
+    _lib.check(_lib.lib().rrtmgp_hip_compute_col_gas(ws.handle, mem, p, array_ptr(out)[0], C.byref(pd),
+                                                     array_ptr(vmr_h2o)[0], array_ptr(lat)[0]), "compute_col_gas")
+    return out
+
+
+def compute_relative_humidity(ws: Workspace, p_lay, t_lay, params, vmr_h2o, out=None):
+    """compute_relative_humidity! (src/optics/column_amounts.jl:52-76) on the device."""
+    if out is None:
+        out = np.empty(julia_shape(p_lay), dtype=array_dtype(p_lay), order="F")
+    p, mem = array_ptr(p_lay)
+    pd = params.desc()
+    _lib.check(_lib.lib().rrtmgp_hip_compute_relative_humidity(ws.handle, mem, array_ptr(out)[0], p,
+                                                               array_ptr(t_lay)[0], C.byref(pd),
+                                                               array_ptr(vmr_h2o)[0]), "compute_relative_humidity")
+    return out

@@ -1,0 +1,275 @@
+"""GPU parity tests: every call goes through the C ABI of libhip_rrtmgp.so and is
+compared with the CPU oracle on the same seeded inputs.
+
+Tolerances (W/m^2 unless noted), from the reference's own CI budget:
+  * Float64 HIP vs Float64 oracle: 1e-8 absolute (the reference asks 1e-4 LW / 1e-3 SW
+    against rte-rrtmgp, test/runtests.jl:46-49; two implementations of the same
+    algorithm differ only by libm ulps, FMA contraction and the g-point summation tree).
+  * Float32 HIP vs Float64 oracle: the reference's F32<->F64 ratchet,
+    test/float32_consistency.jl:53-62: LW 1e-3, clear SW 3e-2, cloudy SW 1.2e-1.
+  * Float32 HIP vs Float32 oracle: LW 1e-3, SW 2e-2 (same budget class; both carry F32 rounding).
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O  # noqa: E402
+from rrtmgp_jl_amd import _abi, _lib, rte, synthetic as S  # noqa: E402
+from rrtmgp_jl_amd.states import (GrayOpticalThicknessOGorman2008, GrayOpticalThicknessSchneider2004, LwBCs,  # noqa: E402
+                                  RRTMGPParameters, SwBCs)
+
+LWN = ("flux_up", "flux_dn", "flux_net")
+SWN = ("flux_up", "flux_dn", "flux_net", "flux_dn_dir")
+
+
+def maxdiff(a, b, names):
+    return max(float(np.abs(a.as_nlev_ncol(n).astype(np.float64) - b.as_nlev_ncol(n).astype(np.float64)).max())
+               for n in names)
+
+
+def hip_lw(as_, bcs, lw, cld=None, aero=None, twostream=True, n_angles=1, **kw):
+    nlay, ncol = as_.dims
+    cls = rte.TwoStreamLWRTE if twostream else rte.NoScatLWRTE
+    layout = kw.pop("layout", _abi.LAYOUT_NLEV_NCOL)
+    slv = cls(ncol, nlay, as_.dtype, bcs, n_gauss_angles=n_angles, layout=layout)
+    return rte.solve_lw(slv, as_, lw, cld, aero, **kw)
+
+
+def hip_sw(as_, bcs, sw, cld=None, aero=None, twostream=True, **kw):
+    nlay, ncol = as_.dims
+    cls = rte.TwoStreamSWRTE if twostream else rte.NoScatSWRTE
+    layout = kw.pop("layout", _abi.LAYOUT_NLEV_NCOL)
+    slv = cls(ncol, nlay, as_.dtype, bcs, layout=layout)
+    return rte.solve_sw(slv, as_, sw, cld, aero, **kw)
+
+
+def test_library_loads_and_sees_gpu():
+    assert _lib.require_gpu() >= 1
+    assert _lib.lib().rrtmgp_hip_version() == b"0.1.0"
+
+
+def test_mcica_stream_matches_spec():
+    for args in [(0, 1, 1, 0, 0), (2026, 77, 200, 1, 3), (2 ** 63 + 5, 10 ** 6, 256, 0, 17)]:
+        assert _lib.lib().rrtmgp_hip_mcica_uniform(*args) == O.mcica_uniform(*args)
+
+
+# ---- Float64: tight parity on every solver / option combination ---------------------------
+@pytest.mark.parametrize("twostream", [True, False])
+@pytest.mark.parametrize("vmr_kind", ["gm", "full"])
+@pytest.mark.parametrize("sky", ["clear", "cloudy", "aerosol"])
+def test_lw_parity_f64(tables64, twostream, vmr_kind, sky):
+    t = tables64
+    as_, lb, _ = S.make_columns(10, 60, np.float64, seed=5, vmr_kind=vmr_kind, clouds=sky != "clear",
+                                aerosols=sky == "aerosol", inc_flux_ngpt=t["lw"].n_gpt if sky == "cloudy" else 0)
+    cld = t["cld_lw"] if sky != "clear" else None
+    aero = t["aero_lw"] if sky == "aerosol" else None
+    ref = O.solve_lw(as_, lb, t["lw"], cld, aero, twostream=twostream)
+    cover_ref = None if cld is None else as_.cloud_state.cld_cover_lw.copy()
+    out = hip_lw(as_, lb, t["lw"], cld, aero, twostream=twostream)
+    assert maxdiff(out, ref, LWN) < 1e-8
+    if cld is not None:
+        np.testing.assert_array_equal(as_.cloud_state.cld_cover_lw, cover_ref)
+
+
+@pytest.mark.parametrize("n_angles", [1, 2, 3, 4])
+def test_lw_noscat_multi_angle_f64(tables64, n_angles):
+    t = tables64
+    as_, lb, _ = S.make_columns(4, 37, np.float64, seed=8)
+    ref = O.solve_lw(as_, lb, t["lw"], t["cld_lw"], twostream=False, n_gauss_angles=n_angles)
+    out = hip_lw(as_, lb, t["lw"], t["cld_lw"], twostream=False, n_angles=n_angles)
+    assert maxdiff(out, ref, LWN) < 1e-8
+
+
+@pytest.mark.parametrize("vmr_kind", ["gm", "full"])
+@pytest.mark.parametrize("sky", ["clear", "cloudy", "aerosol"])
+def test_sw_2stream_parity_f64(tables64, vmr_kind, sky):
+    t = tables64
+    as_, _, sb = S.make_columns(12, 60, np.float64, seed=6, vmr_kind=vmr_kind, clouds=sky != "clear",
+                                aerosols=sky == "aerosol", night_fraction=0.3)
+    cld = t["cld_sw"] if sky != "clear" else None
+    aero = dataclasses.replace(t["aero_sw"], iband_550nm=10) if sky == "aerosol" else None
+    ref = O.solve_sw(as_, sb, t["sw"], cld, aero)
+    cover_ref = None if cld is None else as_.cloud_state.cld_cover_sw.copy()
+    aod_ref = None if aero is None else (as_.aerosol_state.aod_sw_ext.copy(), as_.aerosol_state.aod_sw_sca.copy())
+    out = hip_sw(as_, sb, t["sw"], cld, aero)
+    assert maxdiff(out, ref, SWN) < 1e-8
+    night = ~(sb.cos_zenith > 0)
+    assert night.any()
+    for n in SWN:
+        assert np.all(out.as_nlev_ncol(n)[:, night] == 0.0)
+    if cld is not None:
+        np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, cover_ref)
+    if aero is not None:
+        np.testing.assert_allclose(as_.aerosol_state.aod_sw_ext, aod_ref[0], rtol=1e-12)
+        np.testing.assert_allclose(as_.aerosol_state.aod_sw_sca, aod_ref[1], rtol=1e-12)
+
+
+def test_sw_noscat_parity_f64(tables64):
+    t = tables64
+    as_, _, sb = S.make_columns(9, 60, np.float64, seed=6, clouds=False, night_fraction=0.3)
+    ref = O.solve_sw(as_, sb, t["sw"], twostream=False)
+    out = hip_sw(as_, sb, t["sw"], twostream=False)
+    assert maxdiff(out, ref, SWN) < 1e-8
+
+
+def test_partial_cloud_fraction_masks_match(tables64):
+    """McICA with 0 < cld_frac < 1: the counter-based stream makes masks, cover and fluxes reproducible
+    across CPU oracle and GPU (stronger than the reference, cloud_optics.jl:253-262)."""
+    t = tables64
+    as_, lb, sb = S.make_columns(16, 48, np.float64, seed=9, random_cld_frac=True, cos_zenith=0.6)
+    for seed, off in [(1, 0), (12345, 1000)]:
+        ref = O.solve_lw(as_, lb, t["lw"], t["cld_lw"], seed=seed, col_offset=off)
+        cref = as_.cloud_state.cld_cover_lw.copy()
+        out = hip_lw(as_, lb, t["lw"], t["cld_lw"], seed=seed, col_offset=off)
+        assert maxdiff(out, ref, LWN) < 1e-8
+        np.testing.assert_array_equal(as_.cloud_state.cld_cover_lw, cref)
+        assert np.any((cref > 0) & (cref < 1))
+        ref = O.solve_sw(as_, sb, t["sw"], t["cld_sw"], seed=seed, col_offset=off)
+        cref = as_.cloud_state.cld_cover_sw.copy()
+        out = hip_sw(as_, sb, t["sw"], t["cld_sw"], seed=seed, col_offset=off)
+        assert maxdiff(out, ref, SWN) < 1e-8
+        np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, cref)
+
+
+def test_reduced_tables_ragged_bands_and_odd_sizes(small_tables64):
+    """Bands of 8/4/12 (LW) and 6/10/4 (SW) g-points, nlay = 3 and 73, ncol = 1 and 5."""
+    t = small_tables64
+    for ncol, nlay in [(1, 3), (5, 73)]:
+        as_, lb, sb = S.make_columns(ncol, nlay, np.float64, seed=21, aerosols=True, n_bnd_lw=3, n_bnd_sw=3,
+                                     night_fraction=0.2, inc_flux_ngpt=t["lw"].n_gpt)
+        for two in (True, False):
+            ref = O.solve_lw(as_, lb, t["lw"], t["cld_lw"], t["aero_lw"], twostream=two)
+            out = hip_lw(as_, lb, t["lw"], t["cld_lw"], t["aero_lw"], twostream=two)
+            assert maxdiff(out, ref, LWN) < 1e-8
+        aero = dataclasses.replace(t["aero_sw"], iband_550nm=2)
+        ref = O.solve_sw(as_, sb, t["sw"], t["cld_sw"], aero)
+        out = hip_sw(as_, sb, t["sw"], t["cld_sw"], aero)
+        assert maxdiff(out, ref, SWN) < 1e-8
+
+
+def test_layouts_metric_and_device_memory(tables64):
+    import torch
+    t = tables64
+    as_, lb, sb = S.make_columns(7, 40, np.float64, seed=4, cos_zenith=0.5)
+    nlay, ncol = as_.dims
+    metric = np.asfortranarray(1.0 + 0.01 * np.arange((nlay + 1) * ncol, dtype=np.float64).reshape(nlay + 1, ncol))
+    ref = O.solve_sw(as_, sb, t["sw"], t["cld_sw"], metric_scaling=metric)
+    a = hip_sw(as_, sb, t["sw"], t["cld_sw"], metric_scaling=metric, layout=_abi.LAYOUT_NCOL_NLEV)
+    assert a.flux_up.shape == (ncol, nlay + 1)
+    assert maxdiff(a, ref, SWN) < 1e-8
+    # device-resident state / BCs / fluxes: pointers used in place, nothing staged
+    dev = torch.device("cuda:0")
+    as_d, sb_d = as_.to_device(dev), sb.to_device(dev)
+    slv = rte.TwoStreamSWRTE(ncol, nlay, np.float64, sb_d, flux_device=dev)
+    slv.ws.use_torch_stream()
+    out = rte.solve_sw(slv, as_d, t["sw"], t["cld_sw"], metric_scaling=torch.from_numpy(metric.T.copy()).to(dev))
+    torch.cuda.synchronize()
+    assert maxdiff(out, ref, SWN) < 1e-8
+    assert slv.ws.last_kernel_ms() > 0
+    np.testing.assert_allclose(as_d.cloud_state.cld_cover_sw.cpu().numpy(), as_.cloud_state.cld_cover_sw)
+
+
+# ---- Float32: the reference's precision ratchet -------------------------------------------
+def test_float32_against_both_oracles(tables64, tables32):
+    as64, lb64, sb64 = S.make_columns(24, 64, np.float64, seed=3, cos_zenith=0.86)
+    as32, lb32, sb32 = S.make_columns(24, 64, np.float32, seed=3, cos_zenith=0.86)
+    for cld_key, tol_lw, tol_sw in [(None, 1e-3, 3e-2), ("cld", 1e-3, 1.2e-1)]:
+        c64 = lambda k: None if cld_key is None else tables64[k]
+        c32 = lambda k: None if cld_key is None else tables32[k]
+        for two in (True, False):
+            out = hip_lw(as32, lb32, tables32["lw"], c32("cld_lw"), twostream=two)
+            assert maxdiff(out, O.solve_lw(as64, lb64, tables64["lw"], c64("cld_lw"), twostream=two), LWN) < tol_lw
+            assert maxdiff(out, O.solve_lw(as32, lb32, tables32["lw"], c32("cld_lw"), twostream=two), LWN) < 1e-3
+        out = hip_sw(as32, sb32, tables32["sw"], c32("cld_sw"))
+        assert maxdiff(out, O.solve_sw(as64, sb64, tables64["sw"], c64("cld_sw")), SWN) < tol_sw
+        assert maxdiff(out, O.solve_sw(as32, sb32, tables32["sw"], c32("cld_sw")), SWN) < 2e-2
+
+
+def test_float32_allsky_with_aerosols(tables64, tables32):
+    as64, lb64, sb64 = S.make_columns(8, 72, np.float64, seed=13, aerosols=True, vmr_kind="full", night_fraction=0.2)
+    as32, lb32, sb32 = S.make_columns(8, 72, np.float32, seed=13, aerosols=True, vmr_kind="full", night_fraction=0.2)
+    out = hip_lw(as32, lb32, tables32["lw"], tables32["cld_lw"], tables32["aero_lw"])
+    assert maxdiff(out, O.solve_lw(as64, lb64, tables64["lw"], tables64["cld_lw"], tables64["aero_lw"]), LWN) < 1e-3
+    out = hip_sw(as32, sb32, tables32["sw"], tables32["cld_sw"], tables32["aero_sw"])
+    assert maxdiff(out, O.solve_sw(as64, sb64, tables64["sw"], tables64["cld_sw"], tables64["aero_sw"]), SWN) < 1.2e-1
+
+
+# ---- gray (config 1) --------------------------------------------------------------------------
+@pytest.mark.parametrize("ft,tol", [(np.float64, 1e-9), (np.float32, 1e-3)])
+def test_gray_solvers(ft, tol):
+    params = RRTMGPParameters()
+    ncol, nlay = 9, 60
+    lat = np.linspace(-90.0, 90.0, ncol)
+    gs = O.setup_gray_as_pr_grid(nlay, lat, 100000.0, 9000.0, GrayOpticalThicknessSchneider2004(), params, ft)
+    lb = LwBCs(np.ones((1, ncol), dtype=ft, order="F"), None)
+    for two in (True, False):
+        ref = O.solve_lw_gray(gs, lb, twostream=two)
+        cls = rte.TwoStreamLWRTE if two else rte.NoScatLWRTE
+        out = rte.solve_lw(cls(ncol, nlay, ft, lb), gs)
+        assert maxdiff(out, ref, LWN) < tol
+    gs2 = O.setup_gray_as_pr_grid(nlay, lat, 100000.0, 9000.0, GrayOpticalThicknessOGorman2008(), params, ft)
+    mu0 = np.full(ncol, np.cos(np.pi / 180 * 52.95), dtype=ft)
+    mu0[3] = 0.0
+    mu0[4] = -0.2
+    sb = SwBCs(mu0, np.full(ncol, 1407.679, dtype=ft), np.full((1, ncol), 0.1, dtype=ft, order="F"),
+               np.full((1, ncol), 0.1, dtype=ft, order="F"))
+    for two in (True, False):
+        ref = O.solve_sw_gray(gs2, sb, twostream=two)
+        cls = rte.TwoStreamSWRTE if two else rte.NoScatSWRTE
+        out = rte.solve_sw(cls(ncol, nlay, ft, sb), gs2)
+        assert maxdiff(out, ref, SWN) < tol
+        assert np.all(out.flux_dn[:, [3, 4]] == 0)
+        ref2 = O.solve_lw_gray(gs2, lb, twostream=two)  # O'Gorman LW optical depth as well
+        cls = rte.TwoStreamLWRTE if two else rte.NoScatLWRTE
+        assert maxdiff(rte.solve_lw(cls(ncol, nlay, ft, lb), gs2), ref2, LWN) < tol
+
+
+def test_col_gas_and_relative_humidity():
+    params = RRTMGPParameters()
+    for ft, rtol in [(np.float64, 1e-13), (np.float32, 1e-5)]:
+        as_, _, _ = S.make_columns(33, 25, ft, seed=2)
+        ws = rte.Workspace(33, 25, ft)
+        h2o = as_.vmr.vmr_h2o
+        np.testing.assert_allclose(rte.compute_col_gas(ws, as_.p_lev, params, h2o, as_.lat),
+                                   O.compute_col_gas(as_.p_lev, params, h2o, as_.lat), rtol=rtol)
+        np.testing.assert_allclose(rte.compute_col_gas(ws, as_.p_lev, params),
+                                   O.compute_col_gas(as_.p_lev, params), rtol=rtol)
+        p_lay, t_lay = np.asfortranarray(as_.layerdata[1]), np.asfortranarray(as_.layerdata[2])
+        np.testing.assert_allclose(rte.compute_relative_humidity(ws, p_lay, t_lay, params, h2o),
+                                   O.compute_relative_humidity(p_lay, t_lay, params, h2o), rtol=rtol)
+
+
+# ---- full-size, size-independent properties (BASELINE config 4 shape) --------------------------
+def test_full_size_properties(tables32):
+    t = tables32
+    ncol, nlay = 4096, 72
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=2026, aerosols=True, night_fraction=0.1)
+    lw = hip_lw(as_, lb, t["lw"], t["cld_lw"], t["aero_lw"])
+    sw = hip_sw(as_, sb, t["sw"], t["cld_sw"], t["aero_sw"])
+    for f, names in ((lw, LWN), (sw, SWN)):
+        for n in names:
+            assert np.all(np.isfinite(getattr(f, n)))
+        np.testing.assert_array_equal(f.flux_net, f.flux_up - f.flux_dn)
+    day = sb.cos_zenith > 0
+    # TOA incoming SW = toa_flux * mu0 (sum of solar_src_scaled is 1)
+    np.testing.assert_allclose(sw.flux_dn[-1, day], (sb.toa_flux * sb.cos_zenith)[day], rtol=2e-5)
+    assert np.all(sw.flux_dn[:, ~day] == 0) and np.all(sw.flux_up[:, ~day] == 0)
+    assert np.all(sw.flux_dn_dir <= sw.flux_dn * (1 + 1e-5) + 1e-4)
+    assert np.all(lw.flux_dn[-1] == 0)  # no incident LW flux
+    assert np.all(lw.flux_up[0] > 0)
+    # column independence: a shard computed on its own reproduces the same columns bit for bit
+    lo, hi = 1000, 1600
+    sh_as, sh_lb, sh_sb = S.make_columns(hi - lo, nlay, np.float32, seed=2026, aerosols=True, night_fraction=0.1,
+                                         col_offset=lo)
+    lw2 = hip_lw(sh_as, sh_lb, t["lw"], t["cld_lw"], t["aero_lw"], col_offset=lo)
+    sw2 = hip_sw(sh_as, sh_sb, t["sw"], t["cld_sw"], t["aero_sw"], col_offset=lo)
+    np.testing.assert_array_equal(lw2.flux_up, lw.flux_up[:, lo:hi])
+    np.testing.assert_array_equal(sw2.flux_dn, sw.flux_dn[:, lo:hi])
+    # spot parity against the oracle on a strided sample of the same columns
+    idx = np.arange(0, ncol, 256)
+    sub = S.make_columns(1, nlay, np.float32, seed=2026, aerosols=True, night_fraction=0.1, col_offset=int(idx[3]))
+    ref = O.solve_lw(sub[0], sub[1], t["lw"], t["cld_lw"], t["aero_lw"], col_offset=int(idx[3]))
+    assert np.abs(ref.flux_up[:, 0] - lw.flux_up[:, idx[3]]).max() < 1e-3
