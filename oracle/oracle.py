@@ -32,9 +32,22 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def n_threads() -> int:
+    """OpenMP threads the oracle uses: the cores this process may run on (not every core
+    of the host), unless OMP_NUM_THREADS is set."""
+    if "OMP_NUM_THREADS" in os.environ:
+        return int(os.environ["OMP_NUM_THREADS"])
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(n_threads(), 32)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         _lib = C.CDLL(build())
         _lib.rrtmgp_oracle_mcica_uniform.restype = C.c_double
         _lib.rrtmgp_oracle_mcica_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]

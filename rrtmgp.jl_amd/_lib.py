@@ -76,6 +76,13 @@ def lib():
             raise RRTMGPHipError(f"{SO_PATH} is missing: run `make -C {CSRC}` (or __graft_entry__.build()). "
                                  "There is no CPU fallback for the product path.")
         try:
+            # When PyTorch is present it must be imported first: its wheel bundles a HIP runtime
+            # with the same SONAME (libamdhip64.so.7), and the library has to share that one
+            # runtime instance to use torch's streams and device tensors in place.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             L = C.CDLL(SO_PATH)
         except OSError as e:
             raise RRTMGPHipError(f"cannot load {SO_PATH}: {e}") from e
