@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--aerosols", action="store_true")
     ap.add_argument("--cld-frac", type=float, default=1.0, help="cloud fraction of cloudy layers (reference benchmark: 1)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="columns for the CPU baseline (0 disables)")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="1: LW and SW kernels on torch's current stream; 2: each on its own stream (concurrent)")
     args = ap.parse_args()
 
     import torch
@@ -86,8 +88,9 @@ def main():
     as_d, lb_d, sb_d = as_h.to_device(dev), lb_h.to_device(dev), sb_h.to_device(dev)
     slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=dev)
     slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=dev)
-    slv_lw.ws.use_torch_stream()
-    slv_sw.ws.use_torch_stream()
+    if args.streams == 1:
+        slv_lw.ws.use_torch_stream()
+        slv_sw.ws.use_torch_stream()
     d_lw, d_lw_cld, d_lw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (lw, cl, al))
     d_sw, d_sw_cld, d_sw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (sw, cs, asw))
 

@@ -250,8 +250,9 @@ int rrtmgp_hip_lookup_destroy(rrtmgp_lookup *lk);
  * (update_fluxes.jl:215-218). */
 int rrtmgp_hip_workspace_create(int device, int64_t ncol, int64_t nlay, int32_t ftype, rrtmgp_workspace **out);
 int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws);
-/* Run this workspace's launches on an existing hipStream_t (e.g. torch's
- * current stream); NULL restores the workspace's own stream. */
+/* Run this workspace's launches on an existing hipStream_t (e.g. torch's current
+ * stream); NULL selects the HIP null (legacy default) stream.  Until this is called a
+ * workspace launches on a private non-blocking stream it creates for itself. */
 int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream);
 /* Block until everything queued on the workspace stream has finished. */
 int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws);

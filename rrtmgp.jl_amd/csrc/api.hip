@@ -573,7 +573,7 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
 
 int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream) {
     RR_CHECK(ws, "null workspace");
-    ws->stream = hip_stream ? (hipStream_t)hip_stream : ws->own_stream;
+    ws->stream = (hipStream_t)hip_stream;  // NULL is the HIP null (legacy default) stream
     return RRTMGP_OK;
 }
 
