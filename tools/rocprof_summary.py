@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases (kernel trace + PMC passes) written by tools/profile.sh
+into a small text file that can be committed under profiles/.
+
+    python tools/rocprof_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt
+"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def q(dbp, sql):
+    db = sqlite3.connect(dbp)
+    try:
+        return db.execute(sql).fetchall()
+    finally:
+        db.close()
+
+
+def main(root):
+    print(f"# rocprofv3 summary of {root}")
+    tr = os.path.join(root, "trace", "bench_results.db")
+    if os.path.exists(tr):
+        print("\n## kernel trace (--kernel-trace --stats): name, calls, total_us, avg_us, pct")
+        for name, calls, tot, avg, pct in q(tr, "select name, total_calls, total_duration, average, percentage from top_kernels limit 8"):
+            print(f"{name[:90]:90s} {calls:6d} {tot:14.1f} {avg:12.1f} {pct:7.2f}")
+        print("\n## dispatch geometry: name, grid, workgroup, lds_size, vgpr, accum_vgpr, sgpr, scratch")
+        for r in q(tr, "select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
+                       "from kernels where name like '%solve_kernel%' group by name"):
+            print("  ", tuple(x if not isinstance(x, str) else x[:60] for x in r))
+    print("\n## PMC passes (--pmc ...): kernel, counter, per-launch average, launches")
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*", "bench_results.db"))):
+        for k, c, s, n in q(d, "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                               "where kernel_name like '%solve_kernel%' group by kernel_name, counter_name"):
+            print(f"{k[:48]:48s} {c:24s} {s / n:20.1f} {n:4d}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
