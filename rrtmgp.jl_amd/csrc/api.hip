@@ -171,6 +171,8 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         }
         RR_CHECK(off == m->n_contrib || m->n_contrib == 0 || off <= m->n_contrib, "minor contributor count mismatch");
         g.m_ncontrib[r] = (int)std::max<int64_t>(m->n_contrib, 1);
+        g.m_nint[r] = (int)m->n_min_absrb;
+        lk->max_int = std::max<int>(lk->max_int, (int)m->n_min_absrb);
         TRY(upload(lk, bst, &g.m_bnd_st[r]));
         TRY(upload(lk, gd, &g.m_gasdata[r]));
         TRY(upload(lk, koff, &g.m_koff[r]));
@@ -497,7 +499,7 @@ int rrtmgp_hip_gas_lookup_create(const rrtmgp_gas_lookup_desc *desc, int device,
     RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
     TRY(select_device(device));
     auto *lk = new rrtmgp_lookup();
-    lk->kind = LK_GAS; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    lk->kind = LK_GAS; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0; lk->max_int = 0;
     int rc = desc->ftype == RRTMGP_F32 ? build_gas<float>(lk, desc, lk->gas32) : build_gas<double>(lk, desc, lk->gas64);
     if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
     *out = lk;
@@ -509,7 +511,7 @@ int rrtmgp_hip_cloud_lookup_create(const rrtmgp_cloud_lookup_desc *desc, int dev
     RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
     TRY(select_device(device));
     auto *lk = new rrtmgp_lookup();
-    lk->kind = LK_CLOUD; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    lk->kind = LK_CLOUD; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0; lk->max_int = 0;
     int rc = desc->ftype == RRTMGP_F32 ? build_cld<float>(lk, desc, lk->cld32) : build_cld<double>(lk, desc, lk->cld64);
     if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
     *out = lk;
@@ -521,7 +523,7 @@ int rrtmgp_hip_aerosol_lookup_create(const rrtmgp_aerosol_lookup_desc *desc, int
     RR_CHECK(desc->ftype == RRTMGP_F32 || desc->ftype == RRTMGP_F64, "ftype must be 4 or 8");
     TRY(select_device(device));
     auto *lk = new rrtmgp_lookup();
-    lk->kind = LK_AEROSOL; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0;
+    lk->kind = LK_AEROSOL; lk->ftype = desc->ftype; lk->device = device; lk->max_minor = 0; lk->max_int = 0;
     int rc = desc->ftype == RRTMGP_F32 ? build_aero<float>(lk, desc, lk->aero32) : build_aero<double>(lk, desc, lk->aero64);
     if (rc) { rrtmgp_hip_lookup_destroy(lk); return rc; }
     *out = lk;
@@ -597,9 +599,9 @@ int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms) {
 #define GAS_DISPATCH(ws, fn, lk, cld, aero, ...)                                                                      \
     ((ws)->ftype == RRTMGP_F32                                                                                        \
          ? fn<float>(ws, twostream, (lk)->gas32, (cld) ? &(cld)->cld32 : nullptr, (aero) ? &(aero)->aero32 : nullptr, \
-                     (lk)->max_minor, __VA_ARGS__)                                                                    \
+                     (lk)->max_int, __VA_ARGS__)                                                                    \
          : fn<double>(ws, twostream, (lk)->gas64, (cld) ? &(cld)->cld64 : nullptr, (aero) ? &(aero)->aero64 : nullptr, \
-                      (lk)->max_minor, __VA_ARGS__))
+                      (lk)->max_int, __VA_ARGS__))
 
 int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
                                     const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,

@@ -39,6 +39,7 @@ struct DevGas {
     const int *m_koff[2];     // [n_bnd] offset of the band's block along the contributor axis
     const FT *m_kminor[2];    // [t][eta][contrib], contrib = koff[b] + i*ng_b + (g - lo_b)
     int m_ncontrib[2];
+    int m_nint[2];            // minor intervals (gasdata columns) per region
     const FT *rayl[2];           // [t][eta][gpt]   (SW)
     const FT *solar_src_scaled;  // [n_gpt]         (SW)
 };
@@ -104,6 +105,7 @@ struct rrtmgp_lookup {
     rrtmgp::DevAero<float> aero32;
     rrtmgp::DevAero<double> aero64;
     int max_minor;  // largest per-band minor count (either region)
+    int max_int;    // largest minor-interval count of either region
 };
 
 struct rrtmgp_workspace {

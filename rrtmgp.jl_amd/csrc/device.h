@@ -1,18 +1,29 @@
 // device.h — device-side building blocks shared by the LW and SW column kernels.
 //
 // Execution model (gfx950): one workgroup per column, one lane per g-point
-// (wavefront w of the group owns g-points 64w..64w+63).  Column data that every
-// g-point needs is staged once per column into LDS by `prepare_column` (lane =
-// layer): the gas table of volume mixing ratios, the T / ln p interpolation
-// indices and fractions (g-point independent), Planck-table positions, cloud and
-// aerosol lookup positions.  The g-point lanes then run the vertical sweeps with
-// all per-lane state in registers and only 4 values per level in the sweep
-// scratch.
+// (wavefront w of the group owns g-points 64w..64w+63, i.e. a few whole bands).
+//
+//  * prepare_column (lane = layer): everything that depends on the layer only —
+//    gas table of volume mixing ratios, T / ln p interpolation indices and
+//    fractions, Planck-table positions, cloud size-table positions, RH position.
+//  * prepare_chunk (lane = (layer, band) pair, CH layers at a time): everything
+//    that depends on (layer, band) but not on the g-point — the binary-species
+//    parameter eta (indices, fractions, column mixing), minor-gas scalings, Planck
+//    band sources, combined cloud and aerosol optical properties.  The reference
+//    recomputes all of this for every g-point (src/optics/gas_optics.jl:129-170,
+//    344-412; cloud_optics.jl:70-244; aerosol_optics.jl:141-431); hoisting it
+//    evaluates the SAME expressions once per band, so results are unchanged.
+//  * the g-point lanes then only gather their 8(+8) major coefficients and the
+//    minor coefficients (coalesced: the tables are re-laid-out g-point-innermost),
+//    combine them with the band records read from LDS, and run the vertical
+//    sweeps with 4 values per level in the sweep scratch.
 #pragma once
 
 #include "common.h"
 
 namespace rrtmgp {
+
+constexpr int CH = 16;  // layers per preparation chunk
 
 // ---- numerics (src/Numerics.jl:24-63), all of the working precision --------------
 template <typename FT> struct Num;
@@ -63,71 +74,109 @@ __host__ __device__ __forceinline__ double mcica_draw(uint64_t key, int draw) {
     return (double)(k >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// ---- wavefront (64-lane) sum, fixed butterfly order => deterministic ----------------
+// ---- wavefront (64-lane) sum over g-points -------------------------------------------
+// DPP butterfly inside each 16-lane row, then row_bcast15 / row_bcast31 across rows;
+// the total lands in lane 63.  Fixed order => bit-reproducible broadband fluxes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename FT>
-__device__ __forceinline__ FT wave_sum(FT v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+__device__ __forceinline__ FT wave_sum_to_lane63(FT v) {
+    v += dpp_mov<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_mov<0x140, 0xF>(v);  // row_mirror      -> every lane holds its row's sum
+    v += dpp_mov<0x142, 0xA>(v);  // row_bcast15 into rows 1, 3
+    v += dpp_mov<0x143, 0xC>(v);  // row_bcast31 into rows 2, 3 -> lane 63 holds the wave sum
     return v;
 }
 
-// ---- LDS carve ----------------------------------------------------------------------
+// ---- dimensions + LDS carve ----------------------------------------------------------
 struct ColDims {
-    int nlay, nlev, ngas1 /* ngas + 1 */, nwaves;
-    int lw, has_cld, has_aero, n_acc /* accumulated flux components per level */;
+    int nlay, nlev, ngas1 /* rows of the gas table */, nwaves, nbnd;
+    int lw, twostream, has_cld, has_aero, n_acc /* accumulated flux components per level */;
+    int max_int; /* largest minor-interval count of either region */
 };
 
 template <typename FT>
 struct ColShared {
-    FT *vmr;  // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
-    FT *col_dry, *p_lay, *t_lay, *rel_hum, *t_lev;
-    FT *fT, *fP, *dens_fact, *dry_fact;
-    int *jT, *jP, *tropo;
-    int *pl_lev_loc, *pl_lay_loc;  // Planck table positions (LW)
+    // ---- whole column, written by prepare_column --------------------------------------
+    FT *vmr;      // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
+    FT *col_dry, *fT, *fP, *dens_fact, *dry_fact, *rel_hum;
+    int *lay_idx;  // jT | jP << 8 | tropo << 16  (0-based lower T index, lower p plane, 0 = lower atmosphere)
+    int *pl_lev_loc, *pl_lay_loc;
     FT *pl_lev_f, *pl_lay_f;
     FT *cld_frac, *path_liq, *path_ice, *liq_fac, *ice_fac;
     int *liq_loc, *ice_loc;
-    FT *aero_mass, *aero_size;  // (15, nlay)
-    FT *rh_f;
     int *rh_loc;
-    unsigned char *aero_bin;  // [10][nlay] size bin (0-based) of the 5 dust + 5 sea-salt species
+    FT *rh_f;
     unsigned char *aero_mask;
+    FT *aod_lay;  // [2][nlay]: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
+    // ---- one chunk of CH layers, written by prepare_chunk --------------------------------
+    int *c_je;                          // [CH][nbnd]: je1 | je2 << 8
+    FT *c_fe1, *c_fe2, *c_cm1, *c_cm2;  // [CH][nbnd]
+    FT *c_mscale;                       // [max_int][CH]
+    FT *c_Blev, *c_Blay;                // [(CH+1)][nbnd], [CH][nbnd]   (LW)
+    FT *c_cld0, *c_cld1, *c_cld2;       // [CH][nbnd]: cloud (tau, ssa, g) or absorption tau
+    FT *c_aer0, *c_aer1, *c_aer2;       // [CH][nbnd]
+    // ---- accumulators -----------------------------------------------------------------------
     FT *acc;    // [nwaves][nlev][n_acc]
-    int *misc;  // [0..nwaves): cloudy g-point count per wave; [nwaves]: pl_sfc_loc; [nwaves+1]: cld start; [nwaves+2]: cld finish
-    FT *miscf;  // [0]: pl_sfc_f; [1..2]: aod ext / sca
+    int *misc;  // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
+    FT *miscf;  // [0]: pl_sfc_f
 };
 
 template <typename T>
 __host__ __device__ inline T *carve(char *&p, size_t n) {
     T *r = reinterpret_cast<T *>(p);
-    size_t b = (n * sizeof(T) + 15) & ~size_t(15);
-    p += b;
+    p += (n * sizeof(T) + 15) & ~size_t(15);
     return r;
 }
 
 template <typename FT>
 __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
     char *p = base;
-    const int nlay = d.nlay, nlev = d.nlev;
+    const int nlay = d.nlay, nlev = d.nlev, nb = d.nbnd;
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * nlay);
-    s.col_dry = carve<FT>(p, nlay); s.p_lay = carve<FT>(p, nlay); s.t_lay = carve<FT>(p, nlay);
-    s.rel_hum = carve<FT>(p, nlay); s.t_lev = carve<FT>(p, nlev);
-    s.fT = carve<FT>(p, nlay); s.fP = carve<FT>(p, nlay); s.dens_fact = carve<FT>(p, nlay);
-    s.dry_fact = carve<FT>(p, nlay);
-    s.jT = carve<int>(p, nlay); s.jP = carve<int>(p, nlay); s.tropo = carve<int>(p, nlay);
-    s.pl_lev_loc = carve<int>(p, nlev); s.pl_lay_loc = carve<int>(p, nlay);
-    s.pl_lev_f = carve<FT>(p, nlev); s.pl_lay_f = carve<FT>(p, nlay);
+    s.col_dry = carve<FT>(p, nlay); s.fT = carve<FT>(p, nlay); s.fP = carve<FT>(p, nlay);
+    s.dens_fact = carve<FT>(p, nlay); s.dry_fact = carve<FT>(p, nlay); s.rel_hum = carve<FT>(p, nlay);
+    s.lay_idx = carve<int>(p, nlay);
+    if (d.lw) {
+        s.pl_lev_loc = carve<int>(p, nlev); s.pl_lev_f = carve<FT>(p, nlev);
+        s.pl_lay_loc = carve<int>(p, nlay); s.pl_lay_f = carve<FT>(p, nlay);
+    }
     if (d.has_cld) {
         s.cld_frac = carve<FT>(p, nlay); s.path_liq = carve<FT>(p, nlay); s.path_ice = carve<FT>(p, nlay);
         s.liq_fac = carve<FT>(p, nlay); s.ice_fac = carve<FT>(p, nlay);
         s.liq_loc = carve<int>(p, nlay); s.ice_loc = carve<int>(p, nlay);
     }
     if (d.has_aero) {
-        s.aero_mass = carve<FT>(p, (size_t)RRTMGP_N_AEROSOLS * nlay);
-        s.aero_size = carve<FT>(p, (size_t)RRTMGP_N_AEROSOLS * nlay);
-        s.rh_f = carve<FT>(p, nlay); s.rh_loc = carve<int>(p, nlay);
-        s.aero_bin = carve<unsigned char>(p, (size_t)10 * nlay);
+        s.rh_loc = carve<int>(p, nlay); s.rh_f = carve<FT>(p, nlay);
         s.aero_mask = carve<unsigned char>(p, nlay);
+        s.aod_lay = carve<FT>(p, (size_t)2 * nlay);
+    }
+    s.c_je = carve<int>(p, (size_t)CH * nb);
+    s.c_fe1 = carve<FT>(p, (size_t)CH * nb); s.c_fe2 = carve<FT>(p, (size_t)CH * nb);
+    s.c_cm1 = carve<FT>(p, (size_t)CH * nb); s.c_cm2 = carve<FT>(p, (size_t)CH * nb);
+    s.c_mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
+    if (d.lw) {
+        s.c_Blev = carve<FT>(p, (size_t)(CH + 1) * nb);
+        s.c_Blay = carve<FT>(p, (size_t)CH * nb);
+    }
+    if (d.has_cld) {
+        s.c_cld0 = carve<FT>(p, (size_t)CH * nb); s.c_cld1 = carve<FT>(p, (size_t)CH * nb);
+        s.c_cld2 = carve<FT>(p, (size_t)CH * nb);
+    }
+    if (d.has_aero) {
+        s.c_aer0 = carve<FT>(p, (size_t)CH * nb); s.c_aer1 = carve<FT>(p, (size_t)CH * nb);
+        s.c_aer2 = carve<FT>(p, (size_t)CH * nb);
     }
     s.acc = carve<FT>(p, (size_t)d.nwaves * nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
@@ -189,15 +238,14 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
     for (int k = tid; k < nlay; k += nt) {
         const FT col_dry = ld[4 * k + 0], p = ld[4 * k + 1], t = ld[4 * k + 2];
-        sh.col_dry[k] = col_dry; sh.p_lay[k] = p; sh.t_lay[k] = t; sh.rel_hum[k] = ld[4 * k + 3];
+        sh.col_dry[k] = col_dry;
+        sh.rel_hum[k] = ld[4 * k + 3];
         const int tropo = p > lk.p_ref_tropo ? 0 : 1;  // gas_optics.jl:188 (0 = lower)
-        sh.tropo[k] = tropo;
         // compute_interp_frac_temp, gas_optics.jl:87-93
         const FT dT = lk.t_ref[1] - lk.t_ref[0];
         const int jT = loc_lower_eq0(t, dT, lk.n_t_ref, lk.t_ref);
-        sh.jT[k] = jT;
         sh.fT[k] = (t - lk.t_ref[jT]) / dT;
-        // compute_interp_frac_press, gas_optics.jl:100-117; jP = 0-based lower pressure plane
+        // compute_interp_frac_press, gas_optics.jl:100-117
         const FT dlp = lk.ln_p_ref[0] - lk.ln_p_ref[1];
         const FT logp = m_log(p);
         int j = (int)((lk.ln_p_ref[0] - logp) / dlp) + 1;
@@ -206,11 +254,10 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         j = j > n_p_ref - 1 ? n_p_ref - 1 : j;
         j += 1;                                          // 1-based jpress
         sh.fP[k] = (lk.ln_p_ref[j - 2] - logp) / dlp;
-        sh.jP[k] = (j + tropo) - 2;                      // (jpress + tropo1 - 1) - 1 -> 0-based lower plane
+        const int jP = (j + tropo) - 2;                  // (jpress + tropo1 - 1) - 1 -> 0-based lower plane
+        sh.lay_idx[k] = jT | (jP << 8) | (tropo << 16);
         sh.dens_fact[k] = FT(0.01) * p / t;              // gas_optics.jl:368-370
-        if (d.lw) {
-            planck_pos(t, lk.t_planck, lk.n_t_plnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]);
-        }
+        if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]);
         if (d.has_cld) {
             const size_t o = (size_t)nlay * col + k;
             sh.cld_frac[k] = as.cld_frac[o];
@@ -220,31 +267,14 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
             cld_pos(as.cld_r_eff_ice[o], cld->radice_lwr, cld->radice_upr, cld->nsize_ice, sh.ice_loc[k], sh.ice_fac[k]);
         }
         if (d.has_aero) {
-            const size_t o = (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
+            const FT *mass = as.aero_mass + (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
             unsigned char any = 0;
-            for (int ia = 0; ia < RRTMGP_N_AEROSOLS; ia++) {
-                const FT m = as.aero_mass[o + ia];
-                sh.aero_mass[RRTMGP_N_AEROSOLS * k + ia] = m;
-                sh.aero_size[RRTMGP_N_AEROSOLS * k + ia] = as.aero_size[o + ia];
-                any |= (m > FT(0));  // compute_aero_mask!, aerosol_optics.jl:464-483
-            }
+            for (int ia = 0; ia < RRTMGP_N_AEROSOLS; ia++) any |= (mass[ia] > FT(0));  // aerosol_optics.jl:464-483
             sh.aero_mask[k] = any;
-            loc_factor_gen(sh.rel_hum[k], aero->rh_levels, aero->nrh, sh.rh_loc[k], sh.rh_f[k]);
-            // locate_merra_size_bin (aerosol_optics.jl:438-451) for dust 1,8..11 and sea salt 2,12..15
-            const int ids[10] = {0, 7, 8, 9, 10, 1, 11, 12, 13, 14};
-            for (int s = 0; s < 10; s++) {
-                const FT sz = as.aero_size[o + ids[s]];
-                int bin = 0;
-                for (int ib = 0; ib < aero->nbin; ib++) {
-                    if (aero->size_bin_limits[2 * ib] <= sz && sz <= aero->size_bin_limits[2 * ib + 1]) { bin = ib; break; }
-                    bin = aero->nbin - 1;
-                }
-                sh.aero_bin[s * nlay + k] = (unsigned char)bin;
-            }
+            loc_factor_gen(ld[4 * k + 3], aero->rh_levels, aero->nrh, sh.rh_loc[k], sh.rh_f[k]);
         }
     }
     // gas table: row ig (1-based gas index), row 0 = 1
-    const int ngas = d.ngas1 - 1;
     for (int i = tid; i < d.ngas1 * nlay; i += nt) {
         const int ig = i / nlay, k = i - ig * nlay;
         FT v;
@@ -258,12 +288,9 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         }
         sh.vmr[i] = v;
     }
-    (void)ngas;
-    for (int k = tid; k < nlev; k += nt) {
-        const FT t = as.t_lev[(size_t)nlev * col + k];
-        sh.t_lev[k] = t;
-        if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, sh.pl_lev_loc[k], sh.pl_lev_f[k]);
-    }
+    if (d.lw)
+        for (int k = tid; k < nlev; k += nt)
+            planck_pos(as.t_lev[(size_t)nlev * col + k], lk.t_planck, lk.n_t_plnk, sh.pl_lev_loc[k], sh.pl_lev_f[k]);
     if (tid == 0) {
         if (d.lw) planck_pos(as.t_sfc[col], lk.t_planck, lk.n_t_plnk, sh.misc[d.nwaves], sh.miscf[0]);
         for (int w = 0; w < d.nwaves; w++) sh.misc[w] = 0;
@@ -282,127 +309,7 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     __syncthreads();
 }
 
-// ---- per-lane band constants ---------------------------------------------------------
-struct LaneBand {
-    int g, ibnd, gi, ngb;
-    int ks[2][2];
-    int m_st[2], m_n[2], m_koff[2];
-};
-
-template <typename FT>
-__device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
-    LaneBand lb;
-    lb.g = g;
-    lb.ibnd = lk.gpt2bnd[g];
-    lb.gi = g - lk.bnd_lo[lb.ibnd];
-    lb.ngb = lk.bnd_ng[lb.ibnd];
-    for (int tr = 0; tr < 2; tr++) {
-        lb.ks[tr][0] = lk.key_species[0 + 2 * (tr + 2 * lb.ibnd)];
-        lb.ks[tr][1] = lk.key_species[1 + 2 * (tr + 2 * lb.ibnd)];
-        lb.m_st[tr] = lk.m_bnd_st[tr][lb.ibnd];
-        lb.m_n[tr] = lk.m_bnd_st[tr][lb.ibnd + 1] - lb.m_st[tr];
-        lb.m_koff[tr] = lk.m_koff[tr][lb.ibnd];
-    }
-    return lb;
-}
-
-// ---- gas optics for one (layer, g-point): src/optics/gas_optics.jl:176-320 -------------
-template <typename FT, bool SW>
-__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k,
-                                           int nlay, FT &tau, FT &ssa, FT &pfrac) {
-    const int tropo = sh.tropo[k];
-    const int jT = sh.jT[k], jP = sh.jP[k];
-    const FT fT = sh.fT[k], fP = sh.fP[k];
-    const FT col_dry = sh.col_dry[k];
-    const int ig0 = lb.ks[tropo][0], ig1 = lb.ks[tropo][1];
-    const FT vmr1 = sh.vmr[ig0 * nlay + k], vmr2 = sh.vmr[ig1 * nlay + k];
-    // compute_interp_frac_eta, gas_optics.jl:129-170
-    const int NE = lk.n_eta, NG = lk.n_gpt;
-    int je[2];
-    FT fe[2], cm[2];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const FT eta_half = lk.vmr_ref[tropo + 2 * (ig0 + lk.n_gases * (jT + it))] /
-                            lk.vmr_ref[tropo + 2 * (ig1 + lk.n_gases * (jT + it))];
-        const FT col_mix = vmr1 + eta_half * vmr2;
-        FT eta = vmr1 * (FT(1) / col_mix);
-        if (col_mix <= FT(0)) eta = FT(0.5);
-        const FT loc_eta = eta * FT(NE - 1);
-        int j = (int)loc_eta;
-        j = j > NE - 2 ? NE - 2 : j;
-        je[it] = j;
-        fe[it] = loc_eta - FT(j);
-        cm[it] = col_mix;
-    }
-    const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe[0], omfe2 = FT(1) - fe[1];
-    // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
-    const size_t sE = (size_t)NG, sP = (size_t)NE * NG, sT = (size_t)lk.n_pp * NE * NG;
-    const size_t b1 = (size_t)jT * sT + (size_t)jP * sP + (size_t)je[0] * sE + lb.g;
-    const size_t b2 = (size_t)(jT + 1) * sT + (size_t)jP * sP + (size_t)je[1] * sE + lb.g;
-    const FT *km = lk.kmajor;
-    const FT tau_major =
-        (cm[0] * (omfP * (omfT * (omfe1 * km[b1] + fe[0] * km[b1 + sE])) +
-                  fP * (omfT * (omfe1 * km[b1 + sP] + fe[0] * km[b1 + sP + sE]))) +
-         cm[1] * (omfP * (fT * (omfe2 * km[b2] + fe[1] * km[b2 + sE])) +
-                  fP * (fT * (omfe2 * km[b2 + sP] + fe[1] * km[b2 + sP + sE])))) *
-        col_dry;
-    // compute_tau_minor, gas_optics.jl:344-412
-    FT tau_minor = FT(0);
-    const int n = lb.m_n[tropo];
-    if (n > 0) {
-        const FT vmr_h2o = sh.vmr[lk.idx_h2o * nlay + k];
-        (void)vmr_h2o;
-        const FT dry_fact = sh.dry_fact[k];
-        const FT density_fact = sh.dens_fact[k];
-        const int *gd = lk.m_gasdata[tropo] + 4 * lb.m_st[tropo];
-        const FT *kmn = lk.m_kminor[tropo];
-        const size_t NC = (size_t)lk.m_ncontrib[tropo];
-        const size_t c0 = (size_t)lb.m_koff[tropo] + lb.gi;
-        for (int i = 0; i < n; i++) {
-            const int idx_gas = gd[4 * i + 0], idx_sgas = gd[4 * i + 1], w_dens = gd[4 * i + 2], by_comp = gd[4 * i + 3];
-            const FT vmr_imnr = sh.vmr[idx_gas * nlay + k];
-            if (vmr_imnr > FT(0)) {
-                FT scaling = vmr_imnr * col_dry;
-                if (w_dens == 1) {
-                    scaling *= density_fact;
-                    if (idx_sgas > 0) {
-                        const FT vs = sh.vmr[idx_sgas * nlay + k];
-                        if (by_comp == 1) scaling *= (FT(1) - vs * dry_fact);
-                        else scaling *= vs * dry_fact;
-                    }
-                }
-                const size_t c = c0 + (size_t)i * lb.ngb;
-                const size_t a1 = ((size_t)jT * NE + je[0]) * NC + c;
-                const size_t a2 = ((size_t)(jT + 1) * NE + je[1]) * NC + c;
-                // interp2d, optics_utils.jl:85-98
-                const FT kv = omfe1 * omfT * kmn[a1] + fe[0] * omfT * kmn[a1 + NC] + omfe2 * fT * kmn[a2] +
-                              fe[1] * fT * kmn[a2 + NC];
-                tau_minor += kv * scaling;
-            }
-        }
-    }
-    if (!SW) {
-        const FT *pf = lk.pfrac;
-        pfrac = (omfP * (omfT * (omfe1 * pf[b1] + fe[0] * pf[b1 + sE])) +
-                 fP * (omfT * (omfe1 * pf[b1 + sP] + fe[0] * pf[b1 + sP + sE]))) +
-                (omfP * (fT * (omfe2 * pf[b2] + fe[1] * pf[b2 + sE])) +
-                 fP * (fT * (omfe2 * pf[b2 + sP] + fe[1] * pf[b2 + sP + sE])));
-        tau = m_max(tau_major + tau_minor, FT(0));
-        ssa = FT(0);
-    } else {
-        // compute_tau_rayleigh, gas_optics.jl:430-444
-        const FT *rc = lk.rayl[tropo];
-        const size_t r1 = ((size_t)jT * NE + je[0]) * NG + lb.g, r2 = ((size_t)(jT + 1) * NE + je[1]) * NG + lb.g;
-        const FT kr = omfe1 * omfT * rc[r1] + fe[0] * omfT * rc[r1 + NG] + omfe2 * fT * rc[r2] + fe[1] * fT * rc[r2 + NG];
-        const FT tau_ray = kr * (sh.vmr[lk.idx_h2o * nlay + k] + FT(1)) * col_dry;
-        tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
-        ssa = tau_ray * (FT(1) / tau);
-        if (tau <= FT(0)) ssa = FT(0);
-        pfrac = FT(0);
-    }
-}
-
-// ---- increment / delta-scale: optics_utils.jl:189-223 ------------------------------------
+// ---- optics_utils.jl:189-223 ---------------------------------------------------------------
 template <typename FT>
 __device__ __forceinline__ void increment_2stream(FT &t1, FT &s1, FT &g1, FT t2, FT s2, FT g2) {
     const FT tau = t1 + t2;
@@ -422,8 +329,7 @@ __device__ __forceinline__ void delta_scale(FT &tau, FT &ssa, FT &g) {
     tau = tau_s; ssa = ssa_s; g = g_s;
 }
 
-// ---- cloud optics for one masked (layer, band): cloud_optics.jl:70-244 ---------------------
-// returns (tau, tau*ssa, tau*ssa*g) of liquid + ice before combination
+// ---- cloud optics of one (layer, band): cloud_optics.jl:154-244 -----------------------------
 template <typename FT>
 __device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShared<FT> &sh, int ibnd, int ice_rgh, int k,
                                             FT &tl, FT &tls, FT &tlsg, FT &ti, FT &tis, FT &tisg) {
@@ -449,25 +355,251 @@ __device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShare
     }
 }
 
+// ---- aerosol optics of one (layer, band): aerosol_optics.jl:141-431 --------------------------
 template <typename FT>
-__device__ __forceinline__ void add_cloud_2stream(const DevCld<FT> &lc, const ColShared<FT> &sh, int ibnd, int ice_rgh,
-                                                  int k, bool delta, FT &tau, FT &ssa, FT &g) {
-    FT tl, tls, tlsg, ti, tis, tisg;
-    cloud_props(lc, sh, ibnd, ice_rgh, k, tl, tls, tlsg, ti, tis, tisg);
-    FT tau_cl = tl + ti;
-    FT ssa_cl = tls + tis;
-    FT g_cl = (tlsg + tisg) / m_max(Num<FT>::eps(), ssa_cl);
-    ssa_cl /= m_max(Num<FT>::eps(), tau_cl);
-    if (delta) delta_scale(tau_cl, ssa_cl, g_cl);
-    increment_2stream(tau, ssa, g, tau_cl, ssa_cl, g_cl);
+__device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT> &sh, const FT *mass, const FT *size,
+                                      int ibnd, int k, FT &tc, FT &tsc, FT &tsgc) {
+    const int nrh = la.nrh, nbin = la.nbin;
+    const int loc = sh.rh_loc[k];
+    const FT f = sh.rh_f[k], omf = FT(1) - f;
+    FT t_cum = FT(0), ts_cum = FT(0), tsg_cum = FT(0);
+    auto size_bin = [&](FT sz) {  // locate_merra_size_bin, aerosol_optics.jl:438-451
+        int bin = 0;
+        for (int ib = 0; ib < nbin; ib++) {
+            if (la.size_bin_limits[2 * ib] <= sz && sz <= la.size_bin_limits[2 * ib + 1]) { bin = ib; break; }
+            bin = nbin - 1;
+        }
+        return bin;
+    };
+    constexpr int dust_ids[5] = {0, 7, 8, 9, 10}, salt_ids[5] = {1, 11, 12, 13, 14};
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const FT m = mass[dust_ids[s]];
+        if (m > FT(0)) {
+            const int bin = size_bin(size[dust_ids[s]]);
+            const FT *tb = la.dust + 3 * ((size_t)bin + (size_t)nbin * ibnd);
+            const FT t = m * tb[0], ts = t * tb[1], tsg = ts * tb[2];
+            t_cum += t; ts_cum += ts; tsg_cum += tsg;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const FT m = mass[salt_ids[s]];
+        if (m > FT(0)) {
+            const int bin = size_bin(size[salt_ids[s]]);
+            const FT *tb = la.sea_salt + 3 * ((size_t)loc + (size_t)nrh * ((size_t)bin + (size_t)nbin * ibnd));
+            const FT t = m * (tb[0] * omf + tb[3] * f);
+            const FT ts = t * (tb[1] * omf + tb[4] * f);
+            const FT tsg = ts * (tb[2] * omf + tb[5] * f);
+            t_cum += t; ts_cum += ts; tsg_cum += tsg;
+        }
+    }
+    auto rh_species = [&](const FT *tab, FT m) {
+        const FT *tb = tab + 3 * ((size_t)loc + (size_t)nrh * ibnd);
+        const FT t = m * (tb[0] * omf + tb[3] * f);
+        const FT ts = t * (tb[1] * omf + tb[4] * f);
+        const FT tsg = ts * (tb[2] * omf + tb[5] * f);
+        t_cum += t; ts_cum += ts; tsg_cum += tsg;
+    };
+    auto dry_species = [&](const FT *tab, FT m) {
+        const FT *tb = tab + 3 * (size_t)ibnd;
+        const FT t = m * tb[0], ts = t * tb[1], tsg = ts * tb[2];
+        t_cum += t; ts_cum += ts; tsg_cum += tsg;
+    };
+    if (mass[2] > FT(0)) rh_species(la.sulfate, mass[2]);
+    if (mass[3] > FT(0)) rh_species(la.black_carbon_rh, mass[3]);
+    if (mass[4] > FT(0)) dry_species(la.black_carbon, mass[4]);
+    if (mass[5] > FT(0)) rh_species(la.organic_carbon_rh, mass[5]);
+    if (mass[6] > FT(0)) dry_species(la.organic_carbon, mass[6]);
+    tc = t_cum; tsc = ts_cum; tsgc = tsg_cum;
 }
 
+// ---- (layer, band) records for layers [k0, k0 + kn) -------------------------------------------
+// Callers synchronise the workgroup before (previous chunk fully consumed) and after.
 template <typename FT>
-__device__ __forceinline__ void add_cloud_1scalar(const DevCld<FT> &lc, const ColShared<FT> &sh, int ibnd, int ice_rgh,
-                                                  int k, FT &tau) {
-    FT tl, tls, tlsg, ti, tis, tisg;
-    cloud_props(lc, sh, ibnd, ice_rgh, k, tl, tls, tlsg, ti, tis, tisg);
-    tau += (tl - tls) + (ti - tis);  // cloud_optics.jl:45
+__device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk,
+                                     const DevCld<FT> *cld, const DevAero<FT> *aero, const DevState<FT> &as, int col,
+                                     int k0, int kn, bool delta) {
+    const int nlay = d.nlay, nb = d.nbnd, tid = threadIdx.x, nt = blockDim.x;
+    const int NE = lk.n_eta;
+    for (int t = tid; t < kn * nb; t += nt) {
+        const int kk = t / nb, b = t - kk * nb, k = k0 + kk;
+        const int li = sh.lay_idx[k];
+        const int jT = li & 0xff, tropo = li >> 16;
+        const int ig0 = lk.key_species[0 + 2 * (tropo + 2 * b)], ig1 = lk.key_species[1 + 2 * (tropo + 2 * b)];
+        const FT vmr1 = sh.vmr[ig0 * nlay + k], vmr2 = sh.vmr[ig1 * nlay + k];
+        // compute_interp_frac_eta, gas_optics.jl:129-170
+        int je[2];
+        FT fe[2], cm[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const FT eta_half = lk.vmr_ref[tropo + 2 * (ig0 + lk.n_gases * (jT + it))] /
+                                lk.vmr_ref[tropo + 2 * (ig1 + lk.n_gases * (jT + it))];
+            const FT col_mix = vmr1 + eta_half * vmr2;
+            FT eta = vmr1 * (FT(1) / col_mix);
+            if (col_mix <= FT(0)) eta = FT(0.5);
+            const FT loc_eta = eta * FT(NE - 1);
+            int j = (int)loc_eta;
+            j = j > NE - 2 ? NE - 2 : j;
+            je[it] = j;
+            fe[it] = loc_eta - FT(j);
+            cm[it] = col_mix;
+        }
+        sh.c_je[t] = je[0] | (je[1] << 8);
+        sh.c_fe1[t] = fe[0]; sh.c_fe2[t] = fe[1]; sh.c_cm1[t] = cm[0]; sh.c_cm2[t] = cm[1];
+        if (d.lw) sh.c_Blay[t] = lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k]] * (FT(1) - sh.pl_lay_f[k]) +
+                                 lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k] + 1] * sh.pl_lay_f[k];
+        if (d.has_cld) {
+            FT c0 = FT(0), c1 = FT(0), c2 = FT(0);
+            if (sh.cld_frac[k] > FT(0)) {
+                FT tl, tls, tlsg, ti, tis, tisg;
+                cloud_props(*cld, sh, b, as.ice_rgh, k, tl, tls, tlsg, ti, tis, tisg);
+                if (d.twostream) {  // add_cloud_optics_2stream!, cloud_optics.jl:120-130
+                    FT tau_cl = tl + ti;
+                    FT ssa_cl = tls + tis;
+                    FT g_cl = (tlsg + tisg) / m_max(Num<FT>::eps(), ssa_cl);
+                    ssa_cl /= m_max(Num<FT>::eps(), tau_cl);
+                    if (delta) delta_scale(tau_cl, ssa_cl, g_cl);
+                    c0 = tau_cl; c1 = ssa_cl; c2 = g_cl;
+                } else {
+                    c0 = (tl - tls) + (ti - tis);  // cloud_optics.jl:45
+                }
+            }
+            sh.c_cld0[t] = c0; sh.c_cld1[t] = c1; sh.c_cld2[t] = c2;
+        }
+        if (d.has_aero) {
+            FT a0 = FT(0), a1 = FT(0), a2 = FT(0);
+            if (sh.aero_mask[k]) {
+                const size_t o = (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
+                FT ta, tsa, tsga;
+                lookup_aerosol(*aero, sh, as.aero_mass + o, as.aero_size + o, b, k, ta, tsa, tsga);
+                if (!d.lw && b == aero->iband_550nm - 1) { sh.aod_lay[k] = ta; sh.aod_lay[nlay + k] = tsa; }
+                if (d.twostream) {  // aerosol_optics.jl:113-122
+                    FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);
+                    FT ssa_aero = tsa / m_max(Num<FT>::eps(), ta);
+                    if (delta) delta_scale(ta, ssa_aero, g_aero);
+                    a0 = ta; a1 = ssa_aero; a2 = g_aero;
+                } else {
+                    a0 = ta - tsa;  // aerosol_optics.jl:45
+                }
+            }
+            sh.c_aer0[t] = a0; sh.c_aer1[t] = a1; sh.c_aer2[t] = a2;
+        }
+    }
+    // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0)
+    for (int t = tid; t < d.max_int * kn; t += nt) {
+        const int i = t / kn, kk = t - i * kn, k = k0 + kk;
+        const int tropo = sh.lay_idx[k] >> 16;
+        FT scaling = FT(0);
+        if (i < lk.m_nint[tropo]) {
+            const int *gd = lk.m_gasdata[tropo] + 4 * i;
+            const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
+            if (vmr_imnr > FT(0)) {
+                scaling = vmr_imnr * sh.col_dry[k];
+                if (gd[2] == 1) {
+                    scaling *= sh.dens_fact[k];
+                    if (gd[1] > 0) {
+                        const FT vs = sh.vmr[gd[1] * nlay + k];
+                        if (gd[3] == 1) scaling *= (FT(1) - vs * sh.dry_fact[k]);
+                        else scaling *= vs * sh.dry_fact[k];
+                    }
+                }
+            }
+        }
+        sh.c_mscale[i * CH + kk] = scaling;
+    }
+    if (d.lw)  // Planck band sources at levels k0 .. k0 + kn  (interp1d_equispaced, compute_optical_props.jl:180-186)
+        for (int t = tid; t < (kn + 1) * nb; t += nt) {
+            const int kk = t / nb, b = t - kk * nb, lev = k0 + kk;
+            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.pl_lev_loc[lev];
+            sh.c_Blev[t] = tp[0] * (FT(1) - sh.pl_lev_f[lev]) + tp[1] * sh.pl_lev_f[lev];
+        }
+}
+
+// ---- per-lane band constants ---------------------------------------------------------
+struct LaneBand {
+    int g, ibnd, gi, ngb;
+    int m_st[2], m_n[2], m_koff[2];
+};
+
+template <typename FT>
+__device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
+    LaneBand lb;
+    lb.g = g;
+    lb.ibnd = lk.gpt2bnd[g];
+    lb.gi = g - lk.bnd_lo[lb.ibnd];
+    lb.ngb = lk.bnd_ng[lb.ibnd];
+    for (int tr = 0; tr < 2; tr++) {
+        lb.m_st[tr] = lk.m_bnd_st[tr][lb.ibnd];
+        lb.m_n[tr] = lk.m_bnd_st[tr][lb.ibnd + 1] - lb.m_st[tr];
+        lb.m_koff[tr] = lk.m_koff[tr][lb.ibnd] + lb.gi;
+    }
+    return lb;
+}
+
+// ---- gas optics of one (layer, g-point): src/optics/gas_optics.jl:176-320 -----------------
+// kk = layer index inside the current chunk.  All table offsets fit 32 bits.
+template <typename FT, bool SW>
+__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
+                                           int nb, int nlay, FT &tau, FT &ssa, FT &pfrac) {
+    const int li = sh.lay_idx[k];
+    const int jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
+    const FT fT = sh.fT[k], fP = sh.fP[k], col_dry = sh.col_dry[k];
+    const int r = kk * nb + lb.ibnd;
+    const int jep = sh.c_je[r];
+    const int je1 = jep & 0xff, je2 = jep >> 8;
+    const FT fe1 = sh.c_fe1[r], fe2 = sh.c_fe2[r], cm1 = sh.c_cm1[r], cm2 = sh.c_cm2[r];
+    const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe1, omfe2 = FT(1) - fe2;
+    const int NE = lk.n_eta, NG = lk.n_gpt;
+    // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
+    const int sE = NG, sP = NE * NG, sT = lk.n_pp * NE * NG;
+    const int b1 = jT * sT + jP * sP + je1 * sE + lb.g;
+    const int b2 = (jT + 1) * sT + jP * sP + je2 * sE + lb.g;
+    const FT *km = lk.kmajor;
+    const FT k000 = km[b1], k100 = km[b1 + sE], k010 = km[b1 + sP], k110 = km[b1 + sP + sE];
+    const FT q000 = km[b2], q100 = km[b2 + sE], q010 = km[b2 + sP], q110 = km[b2 + sP + sE];
+    FT p000, p100, p010, p110, r000, r100, r010, r110;
+    if (!SW) {
+        const FT *pf = lk.pfrac;
+        p000 = pf[b1]; p100 = pf[b1 + sE]; p010 = pf[b1 + sP]; p110 = pf[b1 + sP + sE];
+        r000 = pf[b2]; r100 = pf[b2 + sE]; r010 = pf[b2 + sP]; r110 = pf[b2 + sP + sE];
+    }
+    const FT tau_major = (cm1 * (omfP * (omfT * (omfe1 * k000 + fe1 * k100)) + fP * (omfT * (omfe1 * k010 + fe1 * k110))) +
+                          cm2 * (omfP * (fT * (omfe2 * q000 + fe2 * q100)) + fP * (fT * (omfe2 * q010 + fe2 * q110)))) *
+                         col_dry;
+    // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk)
+    FT tau_minor = FT(0);
+    const int n = lb.m_n[tropo];
+    if (n > 0) {
+        const FT *kmn = lk.m_kminor[tropo];
+        const int NC = lk.m_ncontrib[tropo];
+        const int a1 = (jT * NE + je1) * NC + lb.m_koff[tropo];
+        const int a2 = ((jT + 1) * NE + je2) * NC + lb.m_koff[tropo];
+        const FT *ms = sh.c_mscale + lb.m_st[tropo] * CH + kk;
+        const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
+        for (int i = 0; i < n; i++) {
+            const int c = i * lb.ngb;
+            // interp2d, optics_utils.jl:85-98
+            const FT kv = w11 * kmn[a1 + c] + w21 * kmn[a1 + NC + c] + w12 * kmn[a2 + c] + w22 * kmn[a2 + NC + c];
+            tau_minor += kv * ms[i * CH];
+        }
+    }
+    if (!SW) {
+        pfrac = (omfP * (omfT * (omfe1 * p000 + fe1 * p100)) + fP * (omfT * (omfe1 * p010 + fe1 * p110))) +
+                (omfP * (fT * (omfe2 * r000 + fe2 * r100)) + fP * (fT * (omfe2 * r010 + fe2 * r110)));
+        tau = m_max(tau_major + tau_minor, FT(0));
+        ssa = FT(0);
+    } else {
+        // compute_tau_rayleigh, gas_optics.jl:430-444
+        const FT *rc = lk.rayl[tropo];
+        const int r1 = (jT * NE + je1) * NG + lb.g, r2 = ((jT + 1) * NE + je2) * NG + lb.g;
+        const FT kr = omfe1 * omfT * rc[r1] + fe1 * omfT * rc[r1 + NG] + omfe2 * fT * rc[r2] + fe2 * fT * rc[r2 + NG];
+        const FT tau_ray = kr * (sh.vmr[lk.idx_h2o * nlay + k] + FT(1)) * col_dry;
+        tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
+        ssa = tau_ray * (FT(1) / tau);
+        if (tau <= FT(0)) ssa = FT(0);
+        pfrac = FT(0);
+    }
 }
 
 // ---- McICA mask for this lane's g-point: cloud_optics.jl:264-334 ----------------------------
@@ -504,78 +636,12 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
     return k < 64 ? ((m0 >> k) & 1ULL) : ((m1 >> (k - 64)) & 1ULL);
 }
 
-// ---- aerosol optics for one masked (layer, band): aerosol_optics.jl:141-431 -----------------
-template <typename FT>
-__device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT> &sh, int ibnd, int k, int nlay, FT &tc,
-                                      FT &tsc, FT &tsgc) {
-    const int NA = RRTMGP_N_AEROSOLS;
-    const FT *mass = sh.aero_mass + NA * k;
-    const int nrh = la.nrh, nbin = la.nbin;
-    const int loc = sh.rh_loc[k];
-    const FT f = sh.rh_f[k], omf = FT(1) - f;
-    FT t_cum = FT(0), ts_cum = FT(0), tsg_cum = FT(0);
-    const int dust_ids[5] = {0, 7, 8, 9, 10}, salt_ids[5] = {1, 11, 12, 13, 14};
-    for (int s = 0; s < 5; s++) {
-        const FT m = mass[dust_ids[s]];
-        if (m > FT(0)) {
-            const int bin = sh.aero_bin[s * nlay + k];
-            const FT *tb = la.dust + 3 * ((size_t)bin + (size_t)nbin * ibnd);
-            const FT t = m * tb[0], ts = t * tb[1], tsg = ts * tb[2];
-            t_cum += t; ts_cum += ts; tsg_cum += tsg;
-        }
-    }
-    for (int s = 0; s < 5; s++) {
-        const FT m = mass[salt_ids[s]];
-        if (m > FT(0)) {
-            const int bin = sh.aero_bin[(5 + s) * nlay + k];
-            const FT *tb = la.sea_salt + 3 * ((size_t)loc + (size_t)nrh * ((size_t)bin + (size_t)nbin * ibnd));
-            const FT t = m * (tb[0] * omf + tb[3] * f);
-            const FT ts = t * (tb[1] * omf + tb[4] * f);
-            const FT tsg = ts * (tb[2] * omf + tb[5] * f);
-            t_cum += t; ts_cum += ts; tsg_cum += tsg;
-        }
-    }
-    auto rh_species = [&](const FT *tab, FT m) {
-        const FT *tb = tab + 3 * ((size_t)loc + (size_t)nrh * ibnd);
-        const FT t = m * (tb[0] * omf + tb[3] * f);
-        const FT ts = t * (tb[1] * omf + tb[4] * f);
-        const FT tsg = ts * (tb[2] * omf + tb[5] * f);
-        t_cum += t; ts_cum += ts; tsg_cum += tsg;
-    };
-    auto dry_species = [&](const FT *tab, FT m) {
-        const FT *tb = tab + 3 * (size_t)ibnd;
-        const FT t = m * tb[0], ts = t * tb[1], tsg = ts * tb[2];
-        t_cum += t; ts_cum += ts; tsg_cum += tsg;
-    };
-    if (mass[2] > FT(0)) rh_species(la.sulfate, mass[2]);
-    if (mass[3] > FT(0)) rh_species(la.black_carbon_rh, mass[3]);
-    if (mass[4] > FT(0)) dry_species(la.black_carbon, mass[4]);
-    if (mass[5] > FT(0)) rh_species(la.organic_carbon_rh, mass[5]);
-    if (mass[6] > FT(0)) dry_species(la.organic_carbon, mass[6]);
-    tc = t_cum; tsc = ts_cum; tsgc = tsg_cum;
-}
-
-// add_aerosol_optics_2stream! body for one layer, aerosol_optics.jl:104-130
-template <typename FT>
-__device__ __forceinline__ void add_aerosol_2stream(const DevAero<FT> &la, const ColShared<FT> &sh, int ibnd, int k,
-                                                    int nlay, bool delta, FT &tau, FT &ssa, FT &g, FT &aod_ext,
-                                                    FT &aod_sca) {
-    FT ta, tsa, tsga;
-    lookup_aerosol(la, sh, ibnd, k, nlay, ta, tsa, tsga);
-    FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);
-    FT ssa_aero = tsa / m_max(Num<FT>::eps(), ta);
-    aod_ext += ta;
-    aod_sca += tsa;
-    if (delta) delta_scale(ta, ssa_aero, g_aero);
-    increment_2stream(tau, ssa, g, ta, ssa_aero, g_aero);
-}
-
 // ---- sweep scratch: 4 values per (level, lane), lane-contiguous ----------------------------
 template <typename FT>
 struct Sweep {
-    FT *base;  // this workgroup's slab
+    FT *base;  // this workgroup's slab, already offset by the lane
     int nt;    // lanes in the workgroup
-    __device__ __forceinline__ FT &at(int lev, int a) const { return base[((size_t)lev * 4 + a) * nt + threadIdx.x]; }
+    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(lev * 4 + a) * nt]; }
 };
 
 // ---- write one column's broadband fluxes ---------------------------------------------------

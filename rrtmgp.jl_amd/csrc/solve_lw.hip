@@ -4,12 +4,13 @@
 // (ext/cuda/rte_longwave_2stream.jl:48-141, rte_longwave_noscat.jl:54-150; bodies
 // src/rte/longwave_2stream.jl, longwave_noscat.jl, src/optics/compute_optical_props.jl:18-245).
 //
-// One workgroup per column, one lane per g-point.  Two-stream: a single
-// bottom-up sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
+// One workgroup per column, one lane per g-point, layers in chunks of CH whose
+// band-level records are prepared cooperatively in LDS (device.h).  Two-stream: a
+// single bottom-up sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
 // reflectance/transmittance and the adding step, and leaves 4 numbers per level
 // (A, B, albedo, src) so that the top-down sweep is two FMAs per level:
 //     F_k = A_k F_{k+1} + B_k ,   U_k = albedo_k F_k + src_k .
-// Broadband fluxes are wavefront sums over g-points (fixed butterfly order).
+// Broadband fluxes are wavefront sums over g-points (fixed DPP order).
 #include "device.h"
 
 namespace rrtmgp {
@@ -43,12 +44,6 @@ __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_s
     }
 }
 
-// Planck band source at a tabulated position: interp1d_equispaced(T, t_planck, totplnk)
-template <typename FT>
-__device__ __forceinline__ FT planck_at(const FT *totplnk_band, int loc, FT f) {
-    return totplnk_band[loc] * (FT(1) - f) + totplnk_band[loc + 1] * f;
-}
-
 template <typename FT>
 struct LwArgs {
     DevGas<FT> lk;
@@ -69,23 +64,18 @@ struct LwArgs {
 // optics of one layer for this lane: gas + cloud + aerosol increments (TwoStream) or absorption only (OneScalar)
 template <typename FT, bool TWOSTREAM>
 __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
-                                                uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
-    const int nlay = a.dims.nlay;
-    gas_optics<FT, false>(a.lk, sh, lb, k, nlay, tau, ssa, pfrac);
+                                                int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
+    const int nb = a.dims.nbnd;
+    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, a.dims.nlay, tau, ssa, pfrac);
     g = FT(0);
+    const int r = kk * nb + lb.ibnd;
     if (a.dims.has_cld && mask_bit(m0, m1, k)) {
-        if (TWOSTREAM) add_cloud_2stream(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, false, tau, ssa, g);
-        else add_cloud_1scalar(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, tau);
+        if (TWOSTREAM) increment_2stream(tau, ssa, g, sh.c_cld0[r], sh.c_cld1[r], sh.c_cld2[r]);
+        else tau += sh.c_cld0[r];
     }
     if (a.dims.has_aero && sh.aero_mask[k]) {
-        if (TWOSTREAM) {
-            FT e = FT(0), s = FT(0);
-            add_aerosol_2stream(a.aero, sh, lb.ibnd, k, nlay, false, tau, ssa, g, e, s);
-        } else {
-            FT ta, tsa, tsga;
-            lookup_aerosol(a.aero, sh, lb.ibnd, k, nlay, ta, tsa, tsga);
-            tau += (ta - tsa);  // aerosol_optics.jl:45
-        }
+        if (TWOSTREAM) increment_2stream(tau, ssa, g, sh.c_aer0[r], sh.c_aer1[r], sh.c_aer2[r]);
+        else tau += sh.c_aer0[r];
     }
 }
 
@@ -95,107 +85,126 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
     const ColDims &d = a.dims;
-    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol;
+    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    const FT *totplnk = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd;
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x, (int)blockDim.x};
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x + tid, (int)blockDim.x};
     const FT amask = active ? FT(1) : FT(0);
+    const int nchunk = (nlay + CH - 1) / CH;
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
         prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
 
         uint64_t m0 = 0, m1 = 0;
-        bool cloudy = false;
         if (d.has_cld) {
             const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 0);
-            cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
+            const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
             const unsigned long long b = __ballot(cloudy);
             if (lane == 0) sh.misc[wave] = __popcll(b);
         }
-        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
+        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
         const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)ncol * g] : FT(0);
         FT *acc = sh.acc + (size_t)wave * nlev * d.n_acc;
+        FT sfc_source = FT(0);
 
         if (TWOSTREAM) {
-            // ---- bottom-up: optics + sources + coefficients + adding (longwave_2stream.jl:273-302) ----
-            FT tau, ssa, gg, pfrac;
-            lw_layer_optics<FT, true>(a, sh, lb, 0, m0, m1, tau, ssa, gg, pfrac);
-            const FT sfc_source = planck_at(totplnk, sh.misc[d.nwaves], sh.miscf[0]) * pfrac;
-            FT B_lev = planck_at(totplnk, sh.pl_lev_loc[1], sh.pl_lev_f[1]);             // B(t_lev[k+1])
-            FT lev_src_bot = planck_at(totplnk, sh.pl_lev_loc[0], sh.pl_lev_f[0]) * pfrac;  // lev_source[1]
-            FT lev_src_inc_prev = B_lev * pfrac;
-            FT albedo = FT(1) - emis;
-            FT src = Num<FT>::pi() * emis * sfc_source;
-            for (int k = 0; k < nlay; k++) {
-                FT tau_n = FT(0), ssa_n = FT(0), g_n = FT(0), lev_src_top, inc_next = FT(0);
-                if (k + 1 < nlay) {
-                    FT pfrac_n;
-                    lw_layer_optics<FT, true>(a, sh, lb, k + 1, m0, m1, tau_n, ssa_n, g_n, pfrac_n);
-                    const FT lev_src_dec = B_lev * pfrac_n;
-                    lev_src_top = m_sqrt(lev_src_inc_prev * lev_src_dec);  // compute_optical_props.jl:189
-                    B_lev = planck_at(totplnk, sh.pl_lev_loc[k + 2], sh.pl_lev_f[k + 2]);
-                    inc_next = B_lev * pfrac_n;
-                } else {
-                    lev_src_top = lev_src_inc_prev;
+            // ---- bottom-up: optics + sources, and one layer behind them coefficients + adding
+            //      (compute_optical_props.jl:163-198, longwave_2stream.jl:273-302) ----
+            FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);   // optics of layer k-1
+            FT lev_src_bot = FT(0), inc_prev = FT(0);         // lev_source[k-1], B(t_lev[k]) * pfrac[k-1]
+            FT albedo = FT(1) - emis, src = FT(0);
+            for (int c = 0; c < nchunk; c++) {
+                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                __syncthreads();
+                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, false);
+                __syncthreads();
+                for (int kk = 0; kk < kn; kk++) {
+                    const int k = k0 + kk;
+                    FT tau, ssa, gg, pfrac;
+                    lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
+                    const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
+                    FT lev_src_k;
+                    if (k == 0) {
+                        const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+                        sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
+                        src = Num<FT>::pi() * emis * sfc_source;
+                        lev_src_k = lev_src_dec;
+                    } else {
+                        lev_src_k = m_sqrt(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
+                        FT Rdif, Tdif, src_up, src_dn;
+                        lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_k, Rdif, Tdif, src_up, src_dn);
+                        const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
+                        sw.at(k - 1, 0) = Tdif * denom;                      // A
+                        sw.at(k - 1, 1) = (Rdif * src + src_dn) * denom;     // B
+                        sw.at(k - 1, 2) = albedo;
+                        sw.at(k - 1, 3) = src;
+                        const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
+                        src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
+                        albedo = albedo_n;
+                    }
+                    lev_src_bot = lev_src_k;
+                    inc_prev = lev_src_inc;
+                    tau_p = tau; ssa_p = ssa; g_p = gg;
                 }
+            }
+            {   // top layer: lev_source[nlev] = lev_src_inc of the last layer
                 FT Rdif, Tdif, src_up, src_dn;
-                lw_2stream_coeffs(tau, ssa, gg, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
-                const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
-                sw.at(k, 0) = Tdif * denom;                          // A_k
-                sw.at(k, 1) = (Rdif * src + src_dn) * denom;         // B_k
-                sw.at(k, 2) = albedo;
-                sw.at(k, 3) = src;
-                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;               // Eq 9
-                src = src_up + Tdif * denom * (src + albedo * src_dn);                 // Eq 11
+                lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, inc_prev, Rdif, Tdif, src_up, src_dn);
+                const FT denom = FT(1) / (FT(1) - Rdif * albedo);
+                sw.at(nlay - 1, 0) = Tdif * denom;
+                sw.at(nlay - 1, 1) = (Rdif * src + src_dn) * denom;
+                sw.at(nlay - 1, 2) = albedo;
+                sw.at(nlay - 1, 3) = src;
+                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
+                src = src_up + Tdif * denom * (src + albedo * src_dn);
                 albedo = albedo_n;
-                lev_src_bot = lev_src_top;
-                lev_src_inc_prev = inc_next;
-                tau = tau_n; ssa = ssa_n; gg = g_n;
             }
             // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
             FT F = inc;
             {
-                const FT up = (F * albedo + src) * amask, dn = F * amask;
-                const FT su = wave_sum(up), sd = wave_sum(dn);
-                if (lane == 0) { acc[(size_t)nlay * 2] = su; acc[(size_t)nlay * 2 + 1] = sd; }
+                const FT su = wave_sum_to_lane63((F * albedo + src) * amask), sd = wave_sum_to_lane63(F * amask);
+                if (lane == 63) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
             }
             for (int k = nlay - 1; k >= 0; k--) {
                 F = sw.at(k, 0) * F + sw.at(k, 1);
                 const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
-                const FT su = wave_sum(up), sd = wave_sum(F * amask);
-                if (lane == 0) { acc[(size_t)k * 2] = su; acc[(size_t)k * 2 + 1] = sd; }
+                const FT su = wave_sum_to_lane63(up), sd = wave_sum_to_lane63(F * amask);
+                if (lane == 63) { acc[k * 2] = su; acc[k * 2 + 1] = sd; }
             }
         } else {
             // ---- no-scattering: optics sweep, then one down + one up transport per angle
             //      (longwave_noscat.jl:45-96, 224-301) ----
-            FT sfc_source = FT(0);
-            {
-                FT lev_src_inc_prev = FT(0);
-                FT B_lev = planck_at(totplnk, sh.pl_lev_loc[0], sh.pl_lev_f[0]);
-                for (int k = 0; k < nlay; k++) {
+            FT inc_prev = FT(0);
+            for (int c = 0; c < nchunk; c++) {
+                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                __syncthreads();
+                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, false);
+                __syncthreads();
+                for (int kk = 0; kk < kn; kk++) {
+                    const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, false>(a, sh, lb, k, m0, m1, tau, ssa, gg, pfrac);
-                    const FT lev_src_dec = B_lev * pfrac;
-                    B_lev = planck_at(totplnk, sh.pl_lev_loc[k + 1], sh.pl_lev_f[k + 1]);
-                    const FT lev_src_inc = B_lev * pfrac;
-                    const FT lay_src = planck_at(totplnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]) * pfrac;
+                    lw_layer_optics<FT, false>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
+                    const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
+                    const FT lay_src = sh.c_Blay[kk * nb + lb.ibnd] * pfrac;
                     FT lev_src;
                     if (k == 0) {
-                        sfc_source = planck_at(totplnk, sh.misc[d.nwaves], sh.miscf[0]) * pfrac;
+                        const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+                        sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
                         lev_src = lev_src_dec;
                     } else {
-                        lev_src = m_sqrt(lev_src_inc_prev * lev_src_dec);
+                        lev_src = m_sqrt(inc_prev * lev_src_dec);
                     }
                     sw.at(k, 0) = tau;
                     sw.at(k, 1) = lay_src;
                     sw.at(k, 2) = lev_src;
-                    lev_src_inc_prev = lev_src_inc;
+                    inc_prev = lev_src_inc;
                 }
-                sw.at(nlay, 2) = lev_src_inc_prev;
             }
+            sw.at(nlay, 2) = inc_prev;
             const FT tthresh = tau_thresh<FT>();
             for (int imu = 0; imu < a.n_angles; imu++) {
                 const FT Ds = a.Ds[imu], w_mu = a.wts[imu];
@@ -203,8 +212,8 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                 FT I = a.inc_flux ? inc / Num<FT>::pi() : FT(0);
                 const bool first = imu == 0;
                 {
-                    const FT sd = wave_sum(I * i2f * amask);
-                    if (lane == 0) acc[(size_t)nlay * 2 + 1] = first ? sd : acc[(size_t)nlay * 2 + 1] + sd;
+                    const FT sd = wave_sum_to_lane63(I * i2f * amask);
+                    if (lane == 63) acc[nlay * 2 + 1] = first ? sd : acc[nlay * 2 + 1] + sd;
                 }
                 for (int k = nlay - 1; k >= 0; k--) {
                     const FT tau_loc = sw.at(k, 0) * Ds;
@@ -214,13 +223,13 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
                     I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT sd = wave_sum(I * i2f * amask);
-                    if (lane == 0) acc[(size_t)k * 2 + 1] = first ? sd : acc[(size_t)k * 2 + 1] + sd;
+                    const FT sd = wave_sum_to_lane63(I * i2f * amask);
+                    if (lane == 63) acc[k * 2 + 1] = first ? sd : acc[k * 2 + 1] + sd;
                 }
                 I = I * (FT(1) - emis) + emis * sfc_source;
                 {
-                    const FT su = wave_sum(I * i2f * amask);
-                    if (lane == 0) acc[0] = first ? su : acc[0] + su;
+                    const FT su = wave_sum_to_lane63(I * i2f * amask);
+                    if (lane == 63) acc[0] = first ? su : acc[0] + su;
                 }
                 for (int lev = 1; lev <= nlay; lev++) {
                     const FT tau_loc = sw.at(lev - 1, 0) * Ds;
@@ -230,8 +239,8 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
                     I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT su = wave_sum(I * i2f * amask);
-                    if (lane == 0) acc[(size_t)lev * 2] = first ? su : acc[(size_t)lev * 2] + su;
+                    const FT su = wave_sum_to_lane63(I * i2f * amask);
+                    if (lane == 63) acc[lev * 2] = first ? su : acc[lev * 2] + su;
                 }
             }
         }
@@ -264,8 +273,7 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
 template <typename FT>
 int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
               const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl, int n_angles,
-              uint64_t seed, int64_t col_offset, int max_minor) {
-    (void)max_minor;
+              uint64_t seed, int64_t col_offset, int max_int) {
     LwArgs<FT> a{};
     a.lk = lk;
     if (cld) a.cld = *cld;
@@ -274,10 +282,12 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     a.seed = seed; a.col_offset = col_offset;
     const int threads = ((lk.n_gpt + 63) / 64) * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
+    RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
-    d.nwaves = threads / 64; d.lw = 1; d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 2;
+    d.nwaves = threads / 64; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
+    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 2; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     a.n_angles = twostream ? 1 : n_angles;

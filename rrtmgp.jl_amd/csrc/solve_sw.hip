@@ -4,7 +4,8 @@
 // (ext/cuda/rte_shortwave_2stream.jl:58-175, rte_shortwave_noscat.jl:54-112; bodies
 // src/rte/shortwave_2stream.jl, shortwave_noscat.jl, src/optics/compute_optical_props.jl:263-388).
 //
-// One workgroup per column, one lane per g-point.  Two-stream runs three sweeps:
+// One workgroup per column, one lane per g-point, layers in chunks of CH whose band-level
+// records are prepared cooperatively in LDS (device.h).  Two-stream runs three sweeps:
 //   1. top-down: gas/cloud/aerosol optics, cumulative direct beam, layer
 //      coefficients -> (Rdif, Tdif, Rdir*dir, Tdir*dir) per layer in the scratch;
 //   2. bottom-up: adding -> (A, B, albedo, src) per level, in place;
@@ -80,17 +81,16 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
     const ColDims &d = a.dims;
-    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol;
+    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x, (int)blockDim.x};
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x + tid, (int)blockDim.x};
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
-    // the 550 nm AOD is the value of the LAST g-point of that band (aerosol_optics.jl:96-116)
-    const bool aod_lane = d.has_aero && a.aero.iband_550nm > 0 && lb.ibnd == a.aero.iband_550nm - 1 &&
-                          lb.gi == lb.ngb - 1 && active;
+    const int nchunk = (nlay + CH - 1) / CH;
+    const bool want_aod = d.has_aero && a.aero.iband_550nm > 0 && a.as.aod_sw_ext != nullptr;
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
         const FT mu0 = a.cos_zenith[col];
@@ -106,15 +106,22 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
             // rte_sw_noscat!, shortwave_noscat.jl:120-148 (multiplicative Beer-Lambert, flux_up = 0)
             FT dir = a.toa_flux[col] * solar_frac * mu0;
             {
-                const FT s = wave_sum(dir * amask);
-                if (lane == 0) { acc[(size_t)nlay * 3] = FT(0); acc[(size_t)nlay * 3 + 1] = s; acc[(size_t)nlay * 3 + 2] = s; }
+                const FT s = wave_sum_to_lane63(dir * amask);
+                if (lane == 63) { acc[nlay * 3] = FT(0); acc[nlay * 3 + 1] = s; acc[nlay * 3 + 2] = s; }
             }
-            for (int k = nlay - 1; k >= 0; k--) {
-                FT tau, ssa, pf;
-                gas_optics<FT, true>(a.lk, sh, lb, k, nlay, tau, ssa, pf);
-                dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
-                const FT s = wave_sum(dir * amask);
-                if (lane == 0) { acc[(size_t)k * 3] = FT(0); acc[(size_t)k * 3 + 1] = s; acc[(size_t)k * 3 + 2] = s; }
+            for (int c = nchunk - 1; c >= 0; c--) {
+                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                __syncthreads();
+                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                __syncthreads();
+                for (int kk = kn - 1; kk >= 0; kk--) {
+                    const int k = k0 + kk;
+                    FT tau, ssa, pf;
+                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, nlay, tau, ssa, pf);
+                    dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
+                    const FT s = wave_sum_to_lane63(dir * amask);
+                    if (lane == 63) { acc[k * 3] = FT(0); acc[k * 3 + 1] = s; acc[k * 3 + 2] = s; }
+                }
             }
             __syncthreads();
             store_column(a.fl, sh, d, col, ncol, false);
@@ -129,7 +136,6 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
             const unsigned long long b = __ballot(cloudy);
             if (lane == 0) sh.misc[wave] = __popcll(b);
         }
-        FT aod_ext = FT(0), aod_sca = FT(0);
 
         if (day) {
             // ---- sweep 1, top-down: optics, direct beam, layer coefficients ----
@@ -137,30 +143,37 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
             const FT inv_mu0 = FT(1) / m_max(mu0, mu0_min<FT>());
             FT tau_cum = FT(0), dir_above = dir_top;
             {
-                const FT s = wave_sum(dir_top * amask);
-                if (lane == 0) acc[(size_t)nlay * 3 + 2] = s;
+                const FT s = wave_sum_to_lane63(dir_top * amask);
+                if (lane == 63) acc[nlay * 3 + 2] = s;
             }
-            for (int k = nlay - 1; k >= 0; k--) {
-                FT tau, ssa, pf, gg = FT(0);
-                gas_optics<FT, true>(a.lk, sh, lb, k, nlay, tau, ssa, pf);
-                if (d.has_cld && mask_bit(m0, m1, k)) add_cloud_2stream(a.cld, sh, lb.ibnd, a.as.ice_rgh, k, true, tau, ssa, gg);
-                if (d.has_aero && sh.aero_mask[k]) add_aerosol_2stream(a.aero, sh, lb.ibnd, k, nlay, true, tau, ssa, gg, aod_ext, aod_sca);
-                tau_cum += tau;
-                const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
-                FT Rdir, Tdir, Rdif, Tdif;
-                sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
-                sw.at(k, 0) = Rdif;
-                sw.at(k, 1) = Tdif;
-                sw.at(k, 2) = Rdir * dir_above;  // src_up_ilev
-                sw.at(k, 3) = Tdir * dir_above;  // src_dn_ilev
-                const FT s = wave_sum(dir_k * amask);
-                if (lane == 0) acc[(size_t)k * 3 + 2] = s;
-                dir_above = dir_k;
+            for (int c = nchunk - 1; c >= 0; c--) {
+                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                __syncthreads();
+                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                __syncthreads();
+                for (int kk = kn - 1; kk >= 0; kk--) {
+                    const int k = k0 + kk, r = kk * nb + lb.ibnd;
+                    FT tau, ssa, pf, gg = FT(0);
+                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, nlay, tau, ssa, pf);
+                    if (d.has_cld && mask_bit(m0, m1, k)) increment_2stream(tau, ssa, gg, sh.c_cld0[r], sh.c_cld1[r], sh.c_cld2[r]);
+                    if (d.has_aero && sh.aero_mask[k]) increment_2stream(tau, ssa, gg, sh.c_aer0[r], sh.c_aer1[r], sh.c_aer2[r]);
+                    tau_cum += tau;
+                    const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
+                    FT Rdir, Tdir, Rdif, Tdif;
+                    sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
+                    sw.at(k, 0) = Rdif;
+                    sw.at(k, 1) = Tdif;
+                    sw.at(k, 2) = Rdir * dir_above;  // src_up_ilev
+                    sw.at(k, 3) = Tdir * dir_above;  // src_dn_ilev
+                    const FT s = wave_sum_to_lane63(dir_k * amask);
+                    if (lane == 63) acc[k * 3 + 2] = s;
+                    dir_above = dir_k;
+                }
             }
             const FT dir_sfc = dir_above;
             // ---- sweep 2, bottom-up: adding (shortwave_2stream.jl:340-361) ----
-            FT albedo = a.alb_dif[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
-            FT src = dir_sfc * a.alb_dir[(size_t)lb.ibnd + (size_t)a.lk.n_bnd * col];
+            FT albedo = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
+            FT src = dir_sfc * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
             for (int k = 0; k < nlay; k++) {
                 const FT Rdif = sw.at(k, 0), Tdif = sw.at(k, 1), src_up = sw.at(k, 2), src_dn = sw.at(k, 3);
                 const FT denom = FT(1) / (FT(1) - Rdif * albedo);
@@ -175,28 +188,32 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
             // ---- sweep 3, top-down: fluxes (shortwave_2stream.jl:363-390); diffuse TOA incident = 0 ----
             FT F = FT(0);
             {
-                const FT su = wave_sum((F * albedo + src) * amask);
-                if (lane == 0) { acc[(size_t)nlay * 3] = su; acc[(size_t)nlay * 3 + 1] = acc[(size_t)nlay * 3 + 2]; }
+                const FT su = wave_sum_to_lane63((F * albedo + src) * amask);
+                if (lane == 63) { acc[nlay * 3] = su; acc[nlay * 3 + 1] = acc[nlay * 3 + 2]; }
             }
             for (int k = nlay - 1; k >= 0; k--) {
                 F = sw.at(k, 0) * F + sw.at(k, 1);
                 const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
-                const FT su = wave_sum(up), sd = wave_sum(F * amask);
-                if (lane == 0) { acc[(size_t)k * 3] = su; acc[(size_t)k * 3 + 1] = sd + acc[(size_t)k * 3 + 2]; }
+                const FT su = wave_sum_to_lane63(up), sd = wave_sum_to_lane63(F * amask);
+                if (lane == 63) { acc[k * 3] = su; acc[k * 3 + 1] = sd + acc[k * 3 + 2]; }
             }
-        } else if (d.has_aero && a.as.aod_sw_ext) {
+        } else if (want_aod) {
             // night column: the reference still runs the optics, so the AOD diagnostic is defined
-            for (int k = 0; k < nlay; k++) {
-                if (sh.aero_mask[k]) {
-                    FT ta, tsa, tsga;
-                    lookup_aerosol(a.aero, sh, lb.ibnd, k, nlay, ta, tsa, tsga);
-                    aod_ext += ta;
-                    aod_sca += tsa;
-                }
+            for (int c = 0; c < nchunk; c++) {
+                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                __syncthreads();
+                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
             }
         }
-        if (aod_lane && a.as.aod_sw_ext) { a.as.aod_sw_ext[col] = aod_ext; a.as.aod_sw_sca[col] = aod_sca; }
         __syncthreads();
+        if (want_aod && tid == 0) {
+            // the 550 nm AOD: sum over masked layers in layer order (aerosol_optics.jl:96-116)
+            FT e = FT(0), s = FT(0);
+            for (int k = 0; k < nlay; k++)
+                if (sh.aero_mask[k]) { e += sh.aod_lay[k]; s += sh.aod_lay[nlay + k]; }
+            a.as.aod_sw_ext[col] = e;
+            a.as.aod_sw_sca[col] = s;
+        }
         store_column(a.fl, sh, d, col, ncol, !day);
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
@@ -212,8 +229,7 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
 template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
               const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
-              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_minor) {
-    (void)max_minor;
+              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_int) {
     SwArgs<FT> a{};
     a.lk = lk;
     if (cld) a.cld = *cld;
@@ -226,7 +242,9 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
-    d.nwaves = threads / 64; d.lw = 0; d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3;
+    RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
+    d.nwaves = threads / 64; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
+    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     ColShared<FT> dummy;
