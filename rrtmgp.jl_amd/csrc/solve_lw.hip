@@ -11,6 +11,8 @@
 // (A, B, albedo, src) so that the top-down sweep is two FMAs per level:
 //     F_k = A_k F_{k+1} + B_k ,   U_k = albedo_k F_k + src_k .
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
+#include <cstdlib>
+
 #include "device.h"
 
 namespace rrtmgp {
@@ -59,6 +61,7 @@ struct LwArgs {
     FT Ds[4], wts[4];
     uint64_t seed;
     int64_t col_offset;
+    int ablate;  // debug only (RRTMGP_HIP_ABLATE): 1 skip down sweep, 2 skip sweep stores, 4 skip coefficients+adding, 8 skip optics
 };
 
 // optics of one layer for this lane: gas + cloud + aerosol increments (TwoStream) or absorption only (OneScalar)
@@ -79,8 +82,10 @@ __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColSh
     }
 }
 
+constexpr int DB = 8;  // levels per batch of the top-down sweeps
+
 template <typename FT, bool TWOSTREAM>
-__global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
@@ -122,8 +127,8 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                 __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
-                    FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    FT tau = FT(0.1), ssa = FT(0), gg = FT(0), pfrac = FT(0.1);
+                    if (!(a.ablate & 8)) lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
                     const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
                     FT lev_src_k;
@@ -134,16 +139,20 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                         lev_src_k = lev_src_dec;
                     } else {
                         lev_src_k = m_sqrt(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
+                        if (!(a.ablate & 4)) {
                         FT Rdif, Tdif, src_up, src_dn;
                         lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_k, Rdif, Tdif, src_up, src_dn);
                         const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
+                        if (!(a.ablate & 2)) {
                         sw.at(k - 1, 0) = Tdif * denom;                      // A
                         sw.at(k - 1, 1) = (Rdif * src + src_dn) * denom;     // B
                         sw.at(k - 1, 2) = albedo;
                         sw.at(k - 1, 3) = src;
+                        }
                         const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
                         src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
                         albedo = albedo_n;
+                        } else { src += tau_p + lev_src_k; }
                     }
                     lev_src_bot = lev_src_k;
                     inc_prev = lev_src_inc;
@@ -168,11 +177,24 @@ __global__ void __launch_bounds__(256) lw_solve_kernel(const LwArgs<FT> a) {
                 const FT su = wave_sum_to_lane63((F * albedo + src) * amask), sd = wave_sum_to_lane63(F * amask);
                 if (lane == 63) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
             }
-            for (int k = nlay - 1; k >= 0; k--) {
-                F = sw.at(k, 0) * F + sw.at(k, 1);
-                const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
-                const FT su = wave_sum_to_lane63(up), sd = wave_sum_to_lane63(F * amask);
-                if (lane == 63) { acc[k * 2] = su; acc[k * 2 + 1] = sd; }
+            if (!(a.ablate & 1))
+            for (int kh = nlay - 1; kh >= 0; kh -= DB) {
+                // DB levels per batch: all 4*DB scratch loads are issued before the dependent FMA chain
+                FT A[DB], B[DB], AL[DB], SR[DB];
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    const int k = kh - j >= 0 ? kh - j : 0;
+                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2); SR[j] = sw.at(k, 3);
+                }
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    if (kh - j >= 0) {
+                        const int k = kh - j;
+                        F = A[j] * F + B[j];
+                        const FT su = wave_sum_to_lane63((F * AL[j] + SR[j]) * amask), sd = wave_sum_to_lane63(F * amask);
+                        if (lane == 63) { acc[k * 2] = su; acc[k * 2 + 1] = sd; }
+                    }
+                }
             }
         } else {
             // ---- no-scattering: optics sweep, then one down + one up transport per angle
@@ -280,6 +302,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     if (aero) a.aero = *aero;
     a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux;
     a.seed = seed; a.col_offset = col_offset;
+    { const char *e = getenv("RRTMGP_HIP_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     const int threads = ((lk.n_gpt + 63) / 64) * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");

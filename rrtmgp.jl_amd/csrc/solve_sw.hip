@@ -75,8 +75,10 @@ struct SwArgs {
     int64_t col_offset;
 };
 
+constexpr int DB = 8;  // levels per batch of the light sweeps
+
 template <typename FT, bool TWOSTREAM>
-__global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
@@ -174,16 +176,29 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
             // ---- sweep 2, bottom-up: adding (shortwave_2stream.jl:340-361) ----
             FT albedo = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
             FT src = dir_sfc * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
-            for (int k = 0; k < nlay; k++) {
-                const FT Rdif = sw.at(k, 0), Tdif = sw.at(k, 1), src_up = sw.at(k, 2), src_dn = sw.at(k, 3);
-                const FT denom = FT(1) / (FT(1) - Rdif * albedo);
-                sw.at(k, 0) = Tdif * denom;
-                sw.at(k, 1) = (Rdif * src + src_dn) * denom;
-                sw.at(k, 2) = albedo;
-                sw.at(k, 3) = src;
-                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
-                src = src_up + Tdif * denom * (src + albedo * src_dn);
-                albedo = albedo_n;
+            for (int kl = 0; kl < nlay; kl += DB) {
+                // DB layers per batch: the scratch loads are issued before the dependent adding chain
+                FT RD[DB], TD[DB], SU[DB], SD[DB];
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    const int k = kl + j < nlay ? kl + j : nlay - 1;
+                    RD[j] = sw.at(k, 0); TD[j] = sw.at(k, 1); SU[j] = sw.at(k, 2); SD[j] = sw.at(k, 3);
+                }
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    if (kl + j < nlay) {
+                        const int k = kl + j;
+                        const FT Rdif = RD[j], Tdif = TD[j], src_up = SU[j], src_dn = SD[j];
+                        const FT denom = FT(1) / (FT(1) - Rdif * albedo);
+                        sw.at(k, 0) = Tdif * denom;
+                        sw.at(k, 1) = (Rdif * src + src_dn) * denom;
+                        sw.at(k, 2) = albedo;
+                        sw.at(k, 3) = src;
+                        const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
+                        src = src_up + Tdif * denom * (src + albedo * src_dn);
+                        albedo = albedo_n;
+                    }
+                }
             }
             // ---- sweep 3, top-down: fluxes (shortwave_2stream.jl:363-390); diffuse TOA incident = 0 ----
             FT F = FT(0);
@@ -191,11 +206,22 @@ __global__ void __launch_bounds__(256) sw_solve_kernel(const SwArgs<FT> a) {
                 const FT su = wave_sum_to_lane63((F * albedo + src) * amask);
                 if (lane == 63) { acc[nlay * 3] = su; acc[nlay * 3 + 1] = acc[nlay * 3 + 2]; }
             }
-            for (int k = nlay - 1; k >= 0; k--) {
-                F = sw.at(k, 0) * F + sw.at(k, 1);
-                const FT up = (F * sw.at(k, 2) + sw.at(k, 3)) * amask;
-                const FT su = wave_sum_to_lane63(up), sd = wave_sum_to_lane63(F * amask);
-                if (lane == 63) { acc[k * 3] = su; acc[k * 3 + 1] = sd + acc[k * 3 + 2]; }
+            for (int kh = nlay - 1; kh >= 0; kh -= DB) {
+                FT A[DB], B[DB], AL[DB], SR[DB];
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    const int k = kh - j >= 0 ? kh - j : 0;
+                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2); SR[j] = sw.at(k, 3);
+                }
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    if (kh - j >= 0) {
+                        const int k = kh - j;
+                        F = A[j] * F + B[j];
+                        const FT su = wave_sum_to_lane63((F * AL[j] + SR[j]) * amask), sd = wave_sum_to_lane63(F * amask);
+                        if (lane == 63) { acc[k * 3] = su; acc[k * 3 + 1] = sd + acc[k * 3 + 2]; }
+                    }
+                }
             }
         } else if (want_aod) {
             // night column: the reference still runs the optics, so the AOD diagnostic is defined
