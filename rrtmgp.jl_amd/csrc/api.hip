@@ -87,6 +87,7 @@ template <typename FT>
 static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<FT> &g) {
     const int64_t NE = d->n_eta, NP = d->n_p_ref + 1, NT = d->n_t_ref, NG = d->n_gpt, NB = d->n_bnd;
     RR_CHECK(NE >= 2 && NP >= 3 && NT >= 2 && NG >= 1 && NB >= 1, "bad gas lookup dimensions");
+    RR_CHECK((double)NE * NP * NT * NG * 16.0 < 4.0e9, "gas lookup too large for 32-bit table offsets");
     RR_CHECK(d->kmajor && d->ln_p_ref && d->t_ref && d->vmr_ref && d->key_species && d->major_gpt2bnd,
              "gas lookup: missing table");
     g.is_sw = d->is_sw; g.n_gpt = (int)NG; g.n_bnd = (int)NB; g.n_eta = (int)NE; g.n_pp = (int)NP; g.n_t_ref = (int)NT;
@@ -112,11 +113,23 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
                 for (int64_t e = 0; e < NE; e++) h[(t * NE + e) * n + dst_of_src[c]] = s[e + NE * (t + NT * c)];
         return upload(lk, h, out);
     };
-    TRY(relayout4(d->kmajor, &g.kmajor));
-    g.pfrac = nullptr; g.t_planck = nullptr; g.tot_planck = nullptr;
-    if (!d->is_sw) {
+    g.t_planck = nullptr; g.tot_planck = nullptr;
+    if (d->is_sw) {
+        TRY(relayout4(d->kmajor, &g.kmajor));
+    } else {
         RR_CHECK(d->planck_fraction && d->t_planck && d->tot_planck && d->n_t_plnk >= 2, "LW lookup: missing Planck tables");
-        TRY(relayout4(d->planck_fraction, &g.pfrac));
+        // (kmajor, planck_fraction) interleaved: one 8-byte (Float32) load per interpolation corner
+        const FT *sk = (const FT *)d->kmajor, *sp = (const FT *)d->planck_fraction;
+        std::vector<FT> h((size_t)2 * NE * NP * NT * NG);
+        for (int64_t gq = 0; gq < NG; gq++)
+            for (int64_t t = 0; t < NT; t++)
+                for (int64_t p = 0; p < NP; p++)
+                    for (int64_t e = 0; e < NE; e++) {
+                        const size_t src = e + NE * (p + NP * (t + NT * gq)), dst = 2 * (((t * NP + p) * NE + e) * NG + gq);
+                        h[dst] = sk[src];
+                        h[dst + 1] = sp[src];
+                    }
+        TRY(upload(lk, h, &g.kmajor));
         TRY(upload_raw<FT>(lk, d->t_planck, d->n_t_plnk, &g.t_planck));
         TRY(upload_raw<FT>(lk, d->tot_planck, d->n_t_plnk * NB, &g.tot_planck));
     }

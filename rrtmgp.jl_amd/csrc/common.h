@@ -22,8 +22,7 @@ template <typename FT>
 struct DevGas {
     int is_sw, n_gpt, n_bnd, n_eta, n_pp /* n_p_ref + 1 */, n_t_ref, n_gases, n_t_plnk, idx_h2o;
     FT p_ref_tropo;
-    const FT *kmajor;      // [t][p][eta][gpt]
-    const FT *pfrac;       // [t][p][eta][gpt]            (LW)
+    const FT *kmajor;      // SW: [t][p][eta][gpt]; LW: [t][p][eta][gpt][2] = (kmajor, planck_fraction) pairs
     const FT *t_planck;    // [n_t_plnk]                  (LW)
     const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
     const FT *ln_p_ref;    // [n_p_ref]

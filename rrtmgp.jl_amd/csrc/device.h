@@ -112,12 +112,19 @@ struct ColDims {
     int max_int; /* largest minor-interval count of either region */
 };
 
+// 4 values read with one ds_read_b128 (Float32) / two (Float64)
+template <typename FT>
+struct alignas(4 * sizeof(FT)) V4 {
+    FT x, y, z, w;
+};
+
 template <typename FT>
 struct ColShared {
     // ---- whole column, written by prepare_column --------------------------------------
-    FT *vmr;      // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
-    FT *col_dry, *fT, *fP, *dens_fact, *dry_fact, *rel_hum;
-    int *lay_idx;  // jT | jP << 8 | tropo << 16  (0-based lower T index, lower p plane, 0 = lower atmosphere)
+    FT *vmr;          // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
+    V4<FT> *lay;      // [nlay]: fT, fP, col_dry, vmr_h2o
+    int *lay_idx;     // jT | jP << 8 | tropo << 16  (0-based lower T index, lower p plane, 0 = lower atmosphere)
+    FT *dens_fact, *dry_fact;
     int *pl_lev_loc, *pl_lay_loc;
     FT *pl_lev_f, *pl_lay_f;
     FT *cld_frac, *path_liq, *path_ice, *liq_fac, *ice_fac;
@@ -127,12 +134,13 @@ struct ColShared {
     unsigned char *aero_mask;
     FT *aod_lay;  // [2][nlay]: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
     // ---- one chunk of CH layers, written by prepare_chunk --------------------------------
-    int *c_je;                          // [CH][nbnd]: je1 | je2 << 8
-    FT *c_fe1, *c_fe2, *c_cm1, *c_cm2;  // [CH][nbnd]
-    FT *c_mscale;                       // [max_int][CH]
-    FT *c_Blev, *c_Blay;                // [(CH+1)][nbnd], [CH][nbnd]   (LW)
-    FT *c_cld0, *c_cld1, *c_cld2;       // [CH][nbnd]: cloud (tau, ssa, g) or absorption tau
-    FT *c_aer0, *c_aer1, *c_aer2;       // [CH][nbnd]
+    int *c_je;        // [CH][nbnd]: je1 | je2 << 8
+    V4<FT> *c_eta;    // [CH][nbnd]: fe1, fe2, cm1, cm2
+    FT *c_mscale;     // [max_int][CH]
+    FT *c_Blev;       // [(CH+1)][nbnd]   (LW)
+    FT *c_Blay;       // [CH][nbnd]       (LW)
+    V4<FT> *c_cld;    // [CH][nbnd]: cloud (tau, ssa, g, -) or (absorption tau, -, -, -)
+    V4<FT> *c_aer;    // [CH][nbnd]
     // ---- accumulators -----------------------------------------------------------------------
     FT *acc;    // [nwaves][nlev][n_acc]
     int *misc;  // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
@@ -150,9 +158,12 @@ template <typename FT>
 __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
     char *p = base;
     const int nlay = d.nlay, nlev = d.nlev, nb = d.nbnd;
+    s.lay = carve<V4<FT>>(p, nlay);
+    s.c_eta = carve<V4<FT>>(p, (size_t)CH * nb);
+    if (d.has_cld) s.c_cld = carve<V4<FT>>(p, (size_t)CH * nb);
+    if (d.has_aero) s.c_aer = carve<V4<FT>>(p, (size_t)CH * nb);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * nlay);
-    s.col_dry = carve<FT>(p, nlay); s.fT = carve<FT>(p, nlay); s.fP = carve<FT>(p, nlay);
-    s.dens_fact = carve<FT>(p, nlay); s.dry_fact = carve<FT>(p, nlay); s.rel_hum = carve<FT>(p, nlay);
+    s.dens_fact = carve<FT>(p, nlay); s.dry_fact = carve<FT>(p, nlay);
     s.lay_idx = carve<int>(p, nlay);
     if (d.lw) {
         s.pl_lev_loc = carve<int>(p, nlev); s.pl_lev_f = carve<FT>(p, nlev);
@@ -169,20 +180,10 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
         s.aod_lay = carve<FT>(p, (size_t)2 * nlay);
     }
     s.c_je = carve<int>(p, (size_t)CH * nb);
-    s.c_fe1 = carve<FT>(p, (size_t)CH * nb); s.c_fe2 = carve<FT>(p, (size_t)CH * nb);
-    s.c_cm1 = carve<FT>(p, (size_t)CH * nb); s.c_cm2 = carve<FT>(p, (size_t)CH * nb);
     s.c_mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
     if (d.lw) {
         s.c_Blev = carve<FT>(p, (size_t)(CH + 1) * nb);
         s.c_Blay = carve<FT>(p, (size_t)CH * nb);
-    }
-    if (d.has_cld) {
-        s.c_cld0 = carve<FT>(p, (size_t)CH * nb); s.c_cld1 = carve<FT>(p, (size_t)CH * nb);
-        s.c_cld2 = carve<FT>(p, (size_t)CH * nb);
-    }
-    if (d.has_aero) {
-        s.c_aer0 = carve<FT>(p, (size_t)CH * nb); s.c_aer1 = carve<FT>(p, (size_t)CH * nb);
-        s.c_aer2 = carve<FT>(p, (size_t)CH * nb);
     }
     s.acc = carve<FT>(p, (size_t)d.nwaves * nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
@@ -244,13 +245,13 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
     for (int k = tid; k < nlay; k += nt) {
         const FT col_dry = ld[4 * k + 0], p = ld[4 * k + 1], t = ld[4 * k + 2];
-        sh.col_dry[k] = col_dry;
-        sh.rel_hum[k] = ld[4 * k + 3];
+        V4<FT> rec;
+        rec.z = col_dry;
         const int tropo = p > lk.p_ref_tropo ? 0 : 1;  // gas_optics.jl:188 (0 = lower)
         // compute_interp_frac_temp, gas_optics.jl:87-93
         const FT dT = lk.t_ref[1] - lk.t_ref[0];
         const int jT = loc_lower_eq0(t, dT, lk.n_t_ref, lk.t_ref);
-        sh.fT[k] = (t - lk.t_ref[jT]) / dT;
+        rec.x = (t - lk.t_ref[jT]) / dT;
         // compute_interp_frac_press, gas_optics.jl:100-117
         const FT dlp = lk.ln_p_ref[0] - lk.ln_p_ref[1];
         const FT logp = m_log(p);
@@ -259,9 +260,17 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         j = j < 1 ? 1 : j;
         j = j > n_p_ref - 1 ? n_p_ref - 1 : j;
         j += 1;                                          // 1-based jpress
-        sh.fP[k] = (lk.ln_p_ref[j - 2] - logp) / dlp;
+        rec.y = (lk.ln_p_ref[j - 2] - logp) / dlp;
         const int jP = (j + tropo) - 2;                  // (jpress + tropo1 - 1) - 1 -> 0-based lower plane
         sh.lay_idx[k] = jT | (jP << 8) | (tropo << 16);
+        {   // vmr_h2o of this layer (get_vmr, VolumeMixingRatios.jl:91-129)
+            const int ig = lk.idx_h2o;
+            if (as.vmr_kind == RRTMGP_VMR_GM)
+                rec.w = ig == 1 ? as.vmr_h2o[(size_t)nlay * col + k] : ig == 3 ? as.vmr_o3[(size_t)nlay * col + k] : as.vmr[ig - 1];
+            else
+                rec.w = as.vmr[(size_t)(ig - 1) + (size_t)as.ngas * ((size_t)k + (size_t)nlay * col)];
+        }
+        sh.lay[k] = rec;
         sh.dens_fact[k] = FT(0.01) * p / t;              // gas_optics.jl:368-370
         if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]);
         if (d.has_cld) {
@@ -303,7 +312,7 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     }
     __syncthreads();
     for (int k = tid; k < nlay; k += nt)
-        sh.dry_fact[k] = FT(1) / (FT(1) + sh.vmr[lk.idx_h2o * nlay + k]);  // gas_optics.jl:367
+        sh.dry_fact[k] = FT(1) / (FT(1) + sh.lay[k].w);  // gas_optics.jl:367
     if (d.has_cld && tid == 0) {
         // _get_start / _get_finish, cloud_optics.jl:310-322 (0-based, -1 when clear)
         int start = -1, finish = -1;
@@ -452,7 +461,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
             cm[it] = col_mix;
         }
         sh.c_je[t] = je[0] | (je[1] << 8);
-        sh.c_fe1[t] = fe[0]; sh.c_fe2[t] = fe[1]; sh.c_cm1[t] = cm[0]; sh.c_cm2[t] = cm[1];
+        sh.c_eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
         if (d.lw) sh.c_Blay[t] = lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k]] * (FT(1) - sh.pl_lay_f[k]) +
                                  lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k] + 1] * sh.pl_lay_f[k];
         if (d.has_cld) {
@@ -471,7 +480,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     c0 = (tl - tls) + (ti - tis);  // cloud_optics.jl:45
                 }
             }
-            sh.c_cld0[t] = c0; sh.c_cld1[t] = c1; sh.c_cld2[t] = c2;
+            sh.c_cld[t] = V4<FT>{c0, c1, c2, FT(0)};
         }
         if (d.has_aero) {
             FT a0 = FT(0), a1 = FT(0), a2 = FT(0);
@@ -489,7 +498,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     a0 = ta - tsa;  // aerosol_optics.jl:45
                 }
             }
-            sh.c_aer0[t] = a0; sh.c_aer1[t] = a1; sh.c_aer2[t] = a2;
+            sh.c_aer[t] = V4<FT>{a0, a1, a2, FT(0)};
         }
     }
     // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0)
@@ -501,7 +510,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
             const int *gd = lk.m_gasdata[tropo] + 4 * i;
             const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
             if (vmr_imnr > FT(0)) {
-                scaling = vmr_imnr * sh.col_dry[k];
+                scaling = vmr_imnr * sh.lay[k].z;
                 if (gd[2] == 1) {
                     scaling *= sh.dens_fact[k];
                     if (gd[1] > 0) {
@@ -544,31 +553,51 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
 }
 
 // ---- gas optics of one (layer, g-point): src/optics/gas_optics.jl:176-320 -----------------
-// kk = layer index inside the current chunk.  All table offsets fit 32 bits.
+// kk = layer index inside the current chunk.  Table reads use 32-bit byte offsets on a
+// wave-uniform base (global_load ... saddr form); every offset fits 32 bits by construction.
+template <typename T>
+__device__ __forceinline__ T ldg(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename FT>
+struct alignas(2 * sizeof(FT)) V2 {
+    FT x, y;
+};
+
 template <typename FT, bool SW>
 __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
-                                           int nb, int nlay, FT &tau, FT &ssa, FT &pfrac) {
+                                           int nb, FT &tau, FT &ssa, FT &pfrac) {
+    constexpr unsigned E = sizeof(FT), EK = SW ? E : 2 * E;  // LW: (kmajor, planck_fraction) pairs
     const int li = sh.lay_idx[k];
-    const int jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
-    const FT fT = sh.fT[k], fP = sh.fP[k], col_dry = sh.col_dry[k];
+    const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
+    const V4<FT> lr = sh.lay[k];
+    const FT fT = lr.x, fP = lr.y, col_dry = lr.z;
     const int r = kk * nb + lb.ibnd;
-    const int jep = sh.c_je[r];
-    const int je1 = jep & 0xff, je2 = jep >> 8;
-    const FT fe1 = sh.c_fe1[r], fe2 = sh.c_fe2[r], cm1 = sh.c_cm1[r], cm2 = sh.c_cm2[r];
+    const unsigned jep = sh.c_je[r];
+    const unsigned je1 = jep & 0xff, je2 = jep >> 8;
+    const V4<FT> er = sh.c_eta[r];
+    const FT fe1 = er.x, fe2 = er.y, cm1 = er.z, cm2 = er.w;
     const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe1, omfe2 = FT(1) - fe2;
-    const int NE = lk.n_eta, NG = lk.n_gpt;
+    const unsigned NE = lk.n_eta, NG = lk.n_gpt;
     // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
-    const unsigned sE = NG, sP = NE * NG, sT = lk.n_pp * NE * NG;
-    const unsigned b1 = jT * sT + jP * sP + je1 * sE + lb.g;
-    const unsigned b2 = (jT + 1) * sT + jP * sP + je2 * sE + lb.g;
-    const FT *km = lk.kmajor;
-    const FT k000 = km[b1], k100 = km[b1 + sE], k010 = km[b1 + sP], k110 = km[b1 + sP + sE];
-    const FT q000 = km[b2], q100 = km[b2 + sE], q010 = km[b2 + sP], q110 = km[b2 + sP + sE];
-    FT p000, p100, p010, p110, r000, r100, r010, r110;
-    if (!SW) {
-        const FT *pf = lk.pfrac;
-        p000 = pf[b1]; p100 = pf[b1 + sE]; p010 = pf[b1 + sP]; p110 = pf[b1 + sP + sE];
-        r000 = pf[b2]; r100 = pf[b2 + sE]; r010 = pf[b2 + sP]; r110 = pf[b2 + sP + sE];
+    const unsigned sE = NG * EK, sP = NE * sE;
+    const unsigned row = (jT * lk.n_pp + jP) * NE;  // (t, p) row, in eta units
+    const unsigned o1 = __umul24(row + je1, sE) + lb.g * EK;
+    const unsigned o2 = __umul24(row + lk.n_pp * NE + je2, sE) + lb.g * EK;
+    FT k000, k100, k010, k110, q000, q100, q010, q110;
+    FT p000 = 0, p100 = 0, p010 = 0, p110 = 0, r000 = 0, r100 = 0, r010 = 0, r110 = 0;
+    if (SW) {
+        k000 = ldg<FT>(lk.kmajor, o1); k100 = ldg<FT>(lk.kmajor, o1 + sE);
+        k010 = ldg<FT>(lk.kmajor, o1 + sP); k110 = ldg<FT>(lk.kmajor, o1 + sP + sE);
+        q000 = ldg<FT>(lk.kmajor, o2); q100 = ldg<FT>(lk.kmajor, o2 + sE);
+        q010 = ldg<FT>(lk.kmajor, o2 + sP); q110 = ldg<FT>(lk.kmajor, o2 + sP + sE);
+    } else {
+        const V2<FT> a = ldg<V2<FT>>(lk.kmajor, o1), b = ldg<V2<FT>>(lk.kmajor, o1 + sE);
+        const V2<FT> c = ldg<V2<FT>>(lk.kmajor, o1 + sP), d = ldg<V2<FT>>(lk.kmajor, o1 + sP + sE);
+        const V2<FT> e = ldg<V2<FT>>(lk.kmajor, o2), f = ldg<V2<FT>>(lk.kmajor, o2 + sE);
+        const V2<FT> g = ldg<V2<FT>>(lk.kmajor, o2 + sP), h = ldg<V2<FT>>(lk.kmajor, o2 + sP + sE);
+        k000 = a.x; k100 = b.x; k010 = c.x; k110 = d.x; q000 = e.x; q100 = f.x; q010 = g.x; q110 = h.x;
+        p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
     }
     const FT tau_major = (cm1 * (omfP * (omfT * (omfe1 * k000 + fe1 * k100)) + fP * (omfT * (omfe1 * k010 + fe1 * k110))) +
                           cm2 * (omfP * (fT * (omfe2 * q000 + fe2 * q100)) + fP * (fT * (omfe2 * q010 + fe2 * q110)))) *
@@ -578,21 +607,23 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const int n = lb.m_n[tropo];
     if (n > 0) {
         const FT *kmn = lk.m_kminor[tropo];
-        const unsigned NC = lk.m_ncontrib[tropo];
-        const unsigned a1 = (jT * NE + je1) * NC + lb.m_koff[tropo];
-        const unsigned a2 = ((jT + 1) * NE + je2) * NC + lb.m_koff[tropo];
+        const unsigned NCb = lk.m_ncontrib[tropo] * E;
+        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.m_koff[tropo] * E;
+        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.m_koff[tropo] * E;
         const FT *ms = sh.c_mscale + lb.m_st[tropo] * CH + kk;
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
         // groups of MG intervals: every load of a group is in flight before the first use; slots past
         // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
         constexpr int MG = 4;
+        const unsigned cstep = lb.ngb * E;
         for (int i0 = 0; i0 < n; i0 += MG) {
             FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
 #pragma unroll
             for (int j = 0; j < MG; j++) {
                 const int i = (i0 + j < n) ? i0 + j : n - 1;
-                const unsigned c = (unsigned)(i * lb.ngb);
-                c11[j] = kmn[a1 + c]; c21[j] = kmn[a1 + NC + c]; c12[j] = kmn[a2 + c]; c22[j] = kmn[a2 + NC + c];
+                const unsigned c = (unsigned)i * cstep;
+                c11[j] = ldg<FT>(kmn, a1 + c); c21[j] = ldg<FT>(kmn, a1 + NCb + c);
+                c12[j] = ldg<FT>(kmn, a2 + c); c22[j] = ldg<FT>(kmn, a2 + NCb + c);
                 sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
             }
 #pragma unroll
@@ -608,9 +639,11 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     } else {
         // compute_tau_rayleigh, gas_optics.jl:430-444
         const FT *rc = lk.rayl[tropo];
-        const unsigned r1 = (jT * NE + je1) * NG + lb.g, r2 = ((jT + 1) * NE + je2) * NG + lb.g;
-        const FT kr = omfe1 * omfT * rc[r1] + fe1 * omfT * rc[r1 + NG] + omfe2 * fT * rc[r2] + fe2 * fT * rc[r2 + NG];
-        const FT tau_ray = kr * (sh.vmr[lk.idx_h2o * nlay + k] + FT(1)) * col_dry;
+        const unsigned sR = NG * E;
+        const unsigned r1 = __umul24(jT * NE + je1, sR) + lb.g * E, r2 = __umul24((jT + 1) * NE + je2, sR) + lb.g * E;
+        const FT kr = omfe1 * omfT * ldg<FT>(rc, r1) + fe1 * omfT * ldg<FT>(rc, r1 + sR) + omfe2 * fT * ldg<FT>(rc, r2) +
+                      fe2 * fT * ldg<FT>(rc, r2 + sR);
+        const FT tau_ray = kr * (lr.w + FT(1)) * col_dry;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
         ssa = tau_ray * (FT(1) / tau);
         if (tau <= FT(0)) ssa = FT(0);
@@ -652,12 +685,12 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
     return k < 64 ? ((m0 >> k) & 1ULL) : ((m1 >> (k - 64)) & 1ULL);
 }
 
-// ---- sweep scratch: 4 values per (level, lane), lane-contiguous ----------------------------
+// ---- sweep scratch: 3 values per (level, lane), lane-contiguous ----------------------------
 template <typename FT>
 struct Sweep {
     FT *base;  // this workgroup's slab, already offset by the lane
     int nt;    // lanes in the workgroup
-    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(unsigned)((lev * 4 + a) * nt)]; }
+    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(unsigned)((lev * 3 + a) * nt)]; }
 };
 
 // ---- write one column's broadband fluxes ---------------------------------------------------

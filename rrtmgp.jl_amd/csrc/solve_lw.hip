@@ -7,12 +7,11 @@
 // One workgroup per column, one lane per g-point, layers in chunks of CH whose
 // band-level records are prepared cooperatively in LDS (device.h).  Two-stream: a
 // single bottom-up sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
-// reflectance/transmittance and the adding step, and leaves 4 numbers per level
-// (A, B, albedo, src) so that the top-down sweep is two FMAs per level:
+// reflectance/transmittance and the adding step, and leaves 3 numbers per level
+// (A, B, albedo; the src term is summed over g-points on the fly) so that the
+// top-down sweep is two FMAs per level:
 //     F_k = A_k F_{k+1} + B_k ,   U_k = albedo_k F_k + src_k .
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
-#include <cstdlib>
-
 #include "device.h"
 
 namespace rrtmgp {
@@ -61,7 +60,6 @@ struct LwArgs {
     FT Ds[4], wts[4];
     uint64_t seed;
     int64_t col_offset;
-    int ablate;  // debug only (RRTMGP_HIP_ABLATE): 1 skip down sweep, 2 skip sweep stores, 4 skip coefficients+adding, 8 skip optics
 };
 
 // optics of one layer for this lane: gas + cloud + aerosol increments (TwoStream) or absorption only (OneScalar)
@@ -69,16 +67,18 @@ template <typename FT, bool TWOSTREAM>
 __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
                                                 int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
     const int nb = a.dims.nbnd;
-    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, a.dims.nlay, tau, ssa, pfrac);
+    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
     g = FT(0);
     const int r = kk * nb + lb.ibnd;
     if (a.dims.has_cld && mask_bit(m0, m1, k)) {
-        if (TWOSTREAM) increment_2stream(tau, ssa, g, sh.c_cld0[r], sh.c_cld1[r], sh.c_cld2[r]);
-        else tau += sh.c_cld0[r];
+        const V4<FT> c = sh.c_cld[r];
+        if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
+        else tau += c.x;
     }
     if (a.dims.has_aero && sh.aero_mask[k]) {
-        if (TWOSTREAM) increment_2stream(tau, ssa, g, sh.c_aer0[r], sh.c_aer1[r], sh.c_aer2[r]);
-        else tau += sh.c_aer0[r];
+        const V4<FT> c = sh.c_aer[r];
+        if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
+        else tau += c.x;
     }
 }
 
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x + tid, (int)blockDim.x};
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x + tid, (int)blockDim.x};
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CH - 1) / CH;
 
@@ -116,10 +116,25 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
 
         if (TWOSTREAM) {
             // ---- bottom-up: optics + sources, and one layer behind them coefficients + adding
-            //      (compute_optical_props.jl:163-198, longwave_2stream.jl:273-302) ----
+            //      (compute_optical_props.jl:163-198, longwave_2stream.jl:273-302).  Per level the
+            //      sweep keeps A, B, albedo; src_k only enters U_k = albedo_k F_k + src_k additively,
+            //      so its g-point sum is taken here instead of being stored. ----
             FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);   // optics of layer k-1
             FT lev_src_bot = FT(0), inc_prev = FT(0);         // lev_source[k-1], B(t_lev[k]) * pfrac[k-1]
             FT albedo = FT(1) - emis, src = FT(0);
+            auto add_layer = [&](int kl, FT lev_src_top) {   // layer kl between levels kl and kl+1
+                FT Rdif, Tdif, src_up, src_dn;
+                lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
+                const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
+                sw.at(kl, 0) = Tdif * denom;                         // A
+                sw.at(kl, 1) = (Rdif * src + src_dn) * denom;        // B
+                sw.at(kl, 2) = albedo;
+                const FT ss = wave_sum_to_lane63(src * amask);
+                if (lane == 63) acc[kl * 2] = ss;
+                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
+                src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
+                albedo = albedo_n;
+            };
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
@@ -127,8 +142,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                 __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
-                    FT tau = FT(0.1), ssa = FT(0), gg = FT(0), pfrac = FT(0.1);
-                    if (!(a.ablate & 8)) lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    FT tau, ssa, gg, pfrac;
+                    lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
                     const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
                     FT lev_src_k;
@@ -139,60 +154,35 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                         lev_src_k = lev_src_dec;
                     } else {
                         lev_src_k = m_sqrt(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
-                        if (!(a.ablate & 4)) {
-                        FT Rdif, Tdif, src_up, src_dn;
-                        lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_k, Rdif, Tdif, src_up, src_dn);
-                        const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
-                        if (!(a.ablate & 2)) {
-                        sw.at(k - 1, 0) = Tdif * denom;                      // A
-                        sw.at(k - 1, 1) = (Rdif * src + src_dn) * denom;     // B
-                        sw.at(k - 1, 2) = albedo;
-                        sw.at(k - 1, 3) = src;
-                        }
-                        const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
-                        src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
-                        albedo = albedo_n;
-                        } else { src += tau_p + lev_src_k; }
+                        add_layer(k - 1, lev_src_k);
                     }
                     lev_src_bot = lev_src_k;
                     inc_prev = lev_src_inc;
                     tau_p = tau; ssa_p = ssa; g_p = gg;
                 }
             }
-            {   // top layer: lev_source[nlev] = lev_src_inc of the last layer
-                FT Rdif, Tdif, src_up, src_dn;
-                lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, inc_prev, Rdif, Tdif, src_up, src_dn);
-                const FT denom = FT(1) / (FT(1) - Rdif * albedo);
-                sw.at(nlay - 1, 0) = Tdif * denom;
-                sw.at(nlay - 1, 1) = (Rdif * src + src_dn) * denom;
-                sw.at(nlay - 1, 2) = albedo;
-                sw.at(nlay - 1, 3) = src;
-                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
-                src = src_up + Tdif * denom * (src + albedo * src_dn);
-                albedo = albedo_n;
-            }
+            add_layer(nlay - 1, inc_prev);  // lev_source[nlev] = lev_src_inc of the last layer
             // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
             FT F = inc;
             {
                 const FT su = wave_sum_to_lane63((F * albedo + src) * amask), sd = wave_sum_to_lane63(F * amask);
                 if (lane == 63) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
             }
-            if (!(a.ablate & 1))
             for (int kh = nlay - 1; kh >= 0; kh -= DB) {
-                // DB levels per batch: all 4*DB scratch loads are issued before the dependent FMA chain
-                FT A[DB], B[DB], AL[DB], SR[DB];
+                // DB levels per batch: all scratch loads are issued before the dependent FMA chain
+                FT A[DB], B[DB], AL[DB];
 #pragma unroll
                 for (int j = 0; j < DB; j++) {
                     const int k = kh - j >= 0 ? kh - j : 0;
-                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2); SR[j] = sw.at(k, 3);
+                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2);
                 }
 #pragma unroll
                 for (int j = 0; j < DB; j++) {
                     if (kh - j >= 0) {
                         const int k = kh - j;
                         F = A[j] * F + B[j];
-                        const FT su = wave_sum_to_lane63((F * AL[j] + SR[j]) * amask), sd = wave_sum_to_lane63(F * amask);
-                        if (lane == 63) { acc[k * 2] = su; acc[k * 2 + 1] = sd; }
+                        const FT su = wave_sum_to_lane63(F * AL[j] * amask), sd = wave_sum_to_lane63(F * amask);
+                        if (lane == 63) { acc[k * 2] += su; acc[k * 2 + 1] = sd; }
                     }
                 }
             }
@@ -302,7 +292,6 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     if (aero) a.aero = *aero;
     a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux;
     a.seed = seed; a.col_offset = col_offset;
-    { const char *e = getenv("RRTMGP_HIP_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     const int threads = ((lk.n_gpt + 63) / 64) * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
@@ -321,7 +310,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
     const int grid = column_grid(ws, as.ncol, threads, lds);
     if (grid < 0) return grid;
-    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 4 * threads * sizeof(FT));
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
     auto kern = twostream ? lw_solve_kernel<FT, true> : lw_solve_kernel<FT, false>;

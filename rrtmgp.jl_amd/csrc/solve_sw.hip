@@ -5,11 +5,10 @@
 // src/rte/shortwave_2stream.jl, shortwave_noscat.jl, src/optics/compute_optical_props.jl:263-388).
 //
 // One workgroup per column, one lane per g-point, layers in chunks of CH whose band-level
-// records are prepared cooperatively in LDS (device.h).  Two-stream runs three sweeps:
-//   1. top-down: gas/cloud/aerosol optics, cumulative direct beam, layer
-//      coefficients -> (Rdif, Tdif, Rdir*dir, Tdir*dir) per layer in the scratch;
-//   2. bottom-up: adding -> (A, B, albedo, src) per level, in place;
-//   3. top-down: F_k = A_k F_{k+1} + B_k, U_k = albedo_k F_k + src_k.
+// records are prepared cooperatively in LDS (device.h).  Two-stream runs two sweeps:
+//   1. top-down: gas/cloud/aerosol optics, cumulative direct beam, layer coefficients and
+//      adding from the top -> (A, B, beta) per level in the scratch;
+//   2. bottom-up: U_{k+1} = A_k U_k + B_k, D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}.
 // Night columns (mu0 <= 0) skip the solve and are zeroed, but still produce the
 // cloud-cover and 550 nm AOD diagnostics as the reference does.
 #include "device.h"
@@ -88,7 +87,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 4 * blockDim.x + tid, (int)blockDim.x};
+    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x + tid, (int)blockDim.x};
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CH - 1) / CH;
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk;
                     FT tau, ssa, pf;
-                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, nlay, tau, ssa, pf);
+                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
                     dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
                     const FT s = wave_sum_to_lane63(dir * amask);
                     if (lane == 63) { acc[k * 3] = FT(0); acc[k * 3 + 1] = s; acc[k * 3 + 2] = s; }
@@ -140,13 +139,24 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
         }
 
         if (day) {
-            // ---- sweep 1, top-down: optics, direct beam, layer coefficients ----
+            // ---- sweep 1, top-down: optics, direct beam, layer coefficients and ADDING FROM THE TOP.
+            // The reference adds from the surface up (albedo/src of everything below a level,
+            // shortwave_2stream.jl:340-361) and then sweeps down; the direct beam, however, is only
+            // known top-down.  The same two-stream layer relations
+            //     U_{k+1} = T U_k + R D_{k+1} + S_up ,   D_k = T D_{k+1} + R U_k + S_dn
+            // are closed here from the top instead: D_k = beta_k U_k + delta_k with beta = delta = 0 at
+            // the top of the domain (no incident diffuse flux, :331),
+            //     den = 1 / (1 - beta_{k+1} R),  beta_k = R + T^2 beta_{k+1} den,
+            //     delta_k = S_dn + T den (delta_{k+1} + beta_{k+1} S_up),
+            // which is the mirror image of Eqs 9-11 and gives the same fluxes.  One sweep fewer, and
+            // 3 stored values per level; delta only enters D additively, so it is summed on the fly. ----
             const FT dir_top = a.toa_flux[col] * solar_frac * mu0;
             const FT inv_mu0 = FT(1) / m_max(mu0, mu0_min<FT>());
             FT tau_cum = FT(0), dir_above = dir_top;
+            FT beta = FT(0), delta = FT(0);
             {
                 const FT s = wave_sum_to_lane63(dir_top * amask);
-                if (lane == 63) acc[nlay * 3 + 2] = s;
+                if (lane == 63) { acc[nlay * 3 + 2] = s; acc[nlay * 3 + 1] = FT(0); }
             }
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
@@ -156,70 +166,49 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk, r = kk * nb + lb.ibnd;
                     FT tau, ssa, pf, gg = FT(0);
-                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, nlay, tau, ssa, pf);
-                    if (d.has_cld && mask_bit(m0, m1, k)) increment_2stream(tau, ssa, gg, sh.c_cld0[r], sh.c_cld1[r], sh.c_cld2[r]);
-                    if (d.has_aero && sh.aero_mask[k]) increment_2stream(tau, ssa, gg, sh.c_aer0[r], sh.c_aer1[r], sh.c_aer2[r]);
+                    gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
+                    if (d.has_cld && mask_bit(m0, m1, k)) { const V4<FT> cr = sh.c_cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
+                    if (d.has_aero && sh.aero_mask[k]) { const V4<FT> cr = sh.c_aer[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
                     tau_cum += tau;
                     const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
                     FT Rdir, Tdir, Rdif, Tdif;
                     sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
-                    sw.at(k, 0) = Rdif;
-                    sw.at(k, 1) = Tdif;
-                    sw.at(k, 2) = Rdir * dir_above;  // src_up_ilev
-                    sw.at(k, 3) = Tdir * dir_above;  // src_dn_ilev
-                    const FT s = wave_sum_to_lane63(dir_k * amask);
-                    if (lane == 63) acc[k * 3 + 2] = s;
+                    const FT s_up = Rdir * dir_above, s_dn = Tdir * dir_above;
+                    const FT den = FT(1) / (FT(1) - beta * Rdif);
+                    sw.at(k, 0) = Tdif * den;                       // U_{k+1} = A U_k + B
+                    sw.at(k, 1) = (Rdif * delta + s_up) * den;
+                    sw.at(k, 2) = beta;                             // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
+                    const FT beta_n = Rdif + Tdif * Tdif * beta * den;
+                    delta = s_dn + Tdif * den * (delta + beta * s_up);
+                    beta = beta_n;
+                    const FT sdir = wave_sum_to_lane63(dir_k * amask), sdel = wave_sum_to_lane63(delta * amask);
+                    if (lane == 63) { acc[k * 3 + 2] = sdir; acc[k * 3 + 1] = sdel; }
                     dir_above = dir_k;
                 }
             }
-            const FT dir_sfc = dir_above;
-            // ---- sweep 2, bottom-up: adding (shortwave_2stream.jl:340-361) ----
-            FT albedo = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
-            FT src = dir_sfc * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
+            // ---- surface: U_1 = alb_dif D_1 + dir_sfc alb_dir, D_1 = beta_1 U_1 + delta_1 ----
+            const FT alb = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
+            const FT sfc_src = dir_above * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
+            FT U = (alb * delta + sfc_src) / (FT(1) - alb * beta);
+            {
+                const FT su = wave_sum_to_lane63(U * amask), sb = wave_sum_to_lane63(beta * U * amask);
+                if (lane == 63) { acc[0] = su; acc[1] = (acc[1] + sb) + acc[2]; }
+            }
+            // ---- sweep 2, bottom-up: fluxes ----
             for (int kl = 0; kl < nlay; kl += DB) {
-                // DB layers per batch: the scratch loads are issued before the dependent adding chain
-                FT RD[DB], TD[DB], SU[DB], SD[DB];
+                FT A[DB], B[DB], BE[DB];
 #pragma unroll
                 for (int j = 0; j < DB; j++) {
                     const int k = kl + j < nlay ? kl + j : nlay - 1;
-                    RD[j] = sw.at(k, 0); TD[j] = sw.at(k, 1); SU[j] = sw.at(k, 2); SD[j] = sw.at(k, 3);
+                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); BE[j] = sw.at(k, 2);
                 }
 #pragma unroll
                 for (int j = 0; j < DB; j++) {
                     if (kl + j < nlay) {
-                        const int k = kl + j;
-                        const FT Rdif = RD[j], Tdif = TD[j], src_up = SU[j], src_dn = SD[j];
-                        const FT denom = FT(1) / (FT(1) - Rdif * albedo);
-                        sw.at(k, 0) = Tdif * denom;
-                        sw.at(k, 1) = (Rdif * src + src_dn) * denom;
-                        sw.at(k, 2) = albedo;
-                        sw.at(k, 3) = src;
-                        const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;
-                        src = src_up + Tdif * denom * (src + albedo * src_dn);
-                        albedo = albedo_n;
-                    }
-                }
-            }
-            // ---- sweep 3, top-down: fluxes (shortwave_2stream.jl:363-390); diffuse TOA incident = 0 ----
-            FT F = FT(0);
-            {
-                const FT su = wave_sum_to_lane63((F * albedo + src) * amask);
-                if (lane == 63) { acc[nlay * 3] = su; acc[nlay * 3 + 1] = acc[nlay * 3 + 2]; }
-            }
-            for (int kh = nlay - 1; kh >= 0; kh -= DB) {
-                FT A[DB], B[DB], AL[DB], SR[DB];
-#pragma unroll
-                for (int j = 0; j < DB; j++) {
-                    const int k = kh - j >= 0 ? kh - j : 0;
-                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2); SR[j] = sw.at(k, 3);
-                }
-#pragma unroll
-                for (int j = 0; j < DB; j++) {
-                    if (kh - j >= 0) {
-                        const int k = kh - j;
-                        F = A[j] * F + B[j];
-                        const FT su = wave_sum_to_lane63((F * AL[j] + SR[j]) * amask), sd = wave_sum_to_lane63(F * amask);
-                        if (lane == 63) { acc[k * 3] = su; acc[k * 3 + 1] = sd + acc[k * 3 + 2]; }
+                        const int lev = kl + j + 1;
+                        U = A[j] * U + B[j];
+                        const FT su = wave_sum_to_lane63(U * amask), sb = wave_sum_to_lane63(BE[j] * U * amask);
+                        if (lane == 63) { acc[lev * 3] = su; acc[lev * 3 + 1] = (acc[lev * 3 + 1] + sb) + acc[lev * 3 + 2]; }
                     }
                 }
             }
@@ -277,7 +266,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
     const int grid = column_grid(ws, as.ncol, threads, lds);
     if (grid < 0) return grid;
-    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 4 * threads * sizeof(FT));
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
     auto kern = twostream ? sw_solve_kernel<FT, true> : sw_solve_kernel<FT, false>;
