@@ -54,7 +54,8 @@ __device__ __forceinline__ void gray_lw_coeffs(FT tau, FT bot, FT top, FT &Rdif,
     const FT gamma1 = D * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
     const FT gamma2 = D * FT(0.5) * ssa * (FT(1) - g);
     const FT k = m_sqrt(m_max(D * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
-    const FT e1 = m_exp(-tau * k), om1 = -m_expm1(-tau * k);
+    FT e1, om1;
+    exp_pair(tau * k, e1, om1);
     const FT om2 = om1 * (FT(1) + e1);
     const FT RT = FT(1) / (k * (FT(1) + e1 * e1) + gamma1 * om2);
     Rdif = RT * gamma2 * om2;
@@ -158,7 +159,9 @@ __device__ __forceinline__ void gray_sw_coeffs(FT tau, FT mu0, FT &Rdir, FT &Tdi
     const FT gamma4 = FT(1) - gamma3;
     const FT alpha1 = gamma1 * gamma4 + gamma2 * gamma3, alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
     const FT k = m_sqrt(m_max(FT(2) * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
-    const FT e1 = m_exp(-tau * k), e2 = e1 * e1, om1 = -m_expm1(-tau * k), om2 = om1 * (FT(1) + e1);
+    FT e1, om1;
+    exp_pair(tau * k, e1, om1);
+    const FT e2 = e1 * e1, om2 = om1 * (FT(1) + e1);
     FT RT = FT(1) / (k * (FT(1) + e2) + gamma1 * om2);
     Rdif = RT * gamma2 * om2;
     Tdif = RT * FT(2) * k * e1;

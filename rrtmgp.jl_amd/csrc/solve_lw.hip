@@ -24,8 +24,8 @@ __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_s
     const FT gamma1 = lw_diff_sec * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
     const FT gamma2 = lw_diff_sec * FT(0.5) * ssa * (FT(1) - g);
     const FT k = m_sqrt(m_max(lw_diff_sec * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
-    const FT e1 = m_exp(-tau * k);
-    const FT om1 = -m_expm1(-tau * k);
+    FT e1, om1;
+    exp_pair(tau * k, e1, om1);
     const FT coeff = e1 * e1;
     const FT one_minus_e2kt = om1 * (FT(1) + e1);
     const FT RT_term = FT(1) / (k * (FT(1) + coeff) + gamma1 * one_minus_e2kt);

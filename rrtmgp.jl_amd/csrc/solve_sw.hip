@@ -25,9 +25,9 @@ __device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, 
     const FT alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
     const FT alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
     const FT k = m_sqrt(m_max(FT(2) * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
-    const FT exp_minusktau = m_exp(-tau * k);
+    FT exp_minusktau, om1;
+    exp_pair(tau * k, exp_minusktau, om1);
     const FT exp_minus2ktau = exp_minusktau * exp_minusktau;
-    const FT om1 = -m_expm1(-tau * k);
     const FT one_minus_e2kt = om1 * (FT(1) + exp_minusktau);
     FT RT_term = FT(1) / (k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
     Rdif = RT_term * gamma2 * one_minus_e2kt;
