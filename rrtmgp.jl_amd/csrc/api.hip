@@ -184,6 +184,7 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         }
         RR_CHECK(off == m->n_contrib || m->n_contrib == 0 || off <= m->n_contrib, "minor contributor count mismatch");
         g.m_ncontrib[r] = (int)std::max<int64_t>(m->n_contrib, 1);
+        RR_CHECK(m->n_min_absrb <= 255, "more than 255 minor-gas intervals per region are not supported");
         g.m_nint[r] = (int)m->n_min_absrb;
         lk->max_int = std::max<int>(lk->max_int, (int)m->n_min_absrb);
         TRY(upload(lk, bst, &g.m_bnd_st[r]));

@@ -472,8 +472,10 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                                      int k0, int kn, bool delta) {
     const int nlay = d.nlay, nb = d.nbnd, tid = threadIdx.x, nt = blockDim.x;
     const int NE = lk.n_eta;
-    for (int t = tid; t < kn * nb; t += nt) {
-        const int kk = t / nb, b = t - kk * nb, k = k0 + kk;
+    for (int u = tid; u < CH * nb; u += nt) {
+        const int b = u / CH, kk = u % CH, k = k0 + kk;  // CH is a power of two
+        if (kk >= kn) continue;
+        const int t = kk * nb + b;
         const int li = sh.lay_idx[k];
         const int jT = li & 0xff, tropo = li >> 16;
         const int ig0 = lk.key_species[0 + 2 * (tropo + 2 * b)], ig1 = lk.key_species[1 + 2 * (tropo + 2 * b)];
@@ -537,12 +539,13 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         }
     }
     // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0)
-    for (int t = tid; t < d.max_int * kn; t += nt) {
-        const int i = t / kn, kk = t - i * kn, k = k0 + kk;
+    for (int t = tid; t < d.max_int * CH; t += nt) {
+        const int i = t / CH, kk = t % CH, k = k0 + kk;
+        if (kk >= kn) continue;
         const int tropo = sh.lay_idx[k] >> 16;
         FT scaling = FT(0);
-        if (i < lk.m_nint[tropo]) {
-            const int *gd = lk.m_gasdata[tropo] + 4 * i;
+        if (i < (tropo ? lk.m_nint[1] : lk.m_nint[0])) {
+            const int *gd = (tropo ? lk.m_gasdata[1] : lk.m_gasdata[0]) + 4 * i;
             const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
             if (vmr_imnr > FT(0)) {
                 scaling = vmr_imnr * sh.lay[k].z;
@@ -559,17 +562,23 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         sh.c_mscale[i * CH + kk] = scaling;
     }
     if (d.lw)  // Planck band sources at levels k0 .. k0 + kn  (interp1d_equispaced, compute_optical_props.jl:180-186)
-        for (int t = tid; t < (kn + 1) * nb; t += nt) {
-            const int kk = t / nb, b = t - kk * nb, lev = k0 + kk;
+        for (int u = tid; u < 2 * CH * nb; u += nt) {
+            const int b = u / (2 * CH), kk = u % (2 * CH), lev = k0 + kk;
+            if (kk > kn) continue;
             const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.pl_lev_loc[lev];
-            sh.c_Blev[t] = tp[0] * (FT(1) - sh.pl_lev_f[lev]) + tp[1] * sh.pl_lev_f[lev];
+            sh.c_Blev[kk * nb + b] = tp[0] * (FT(1) - sh.pl_lev_f[lev]) + tp[1] * sh.pl_lev_f[lev];
         }
 }
 
 // ---- per-lane band constants ---------------------------------------------------------
+// (explicit lower/upper members: arrays indexed by the run-time region would live in scratch memory)
 struct LaneBand {
-    int g, ibnd, gi, ngb;
-    int m_st[2], m_n[2], m_koff[2];
+    int g, ibnd, ngb;
+    int m_pack;  // st0 | n0 << 8 | st1 << 16 | n1 << 24   (minor-interval start / count per region)
+    int m_koff0, m_koff1;
+    __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }
+    __device__ __forceinline__ int m_n(unsigned tropo) const { return (m_pack >> (tropo ? 24 : 8)) & 0xff; }
+    __device__ __forceinline__ int m_koff(unsigned tropo) const { return tropo ? m_koff1 : m_koff0; }
 };
 
 template <typename FT>
@@ -577,13 +586,13 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     LaneBand lb;
     lb.g = g;
     lb.ibnd = lk.gpt2bnd[g];
-    lb.gi = g - lk.bnd_lo[lb.ibnd];
+    const int gi = g - lk.bnd_lo[lb.ibnd];
     lb.ngb = lk.bnd_ng[lb.ibnd];
-    for (int tr = 0; tr < 2; tr++) {
-        lb.m_st[tr] = lk.m_bnd_st[tr][lb.ibnd];
-        lb.m_n[tr] = lk.m_bnd_st[tr][lb.ibnd + 1] - lb.m_st[tr];
-        lb.m_koff[tr] = lk.m_koff[tr][lb.ibnd] + lb.gi;
-    }
+    const int st0 = lk.m_bnd_st[0][lb.ibnd], st1 = lk.m_bnd_st[1][lb.ibnd];
+    const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - st0, n1 = lk.m_bnd_st[1][lb.ibnd + 1] - st1;
+    lb.m_pack = st0 | (n0 << 8) | (st1 << 16) | (n1 << 24);
+    lb.m_koff0 = lk.m_koff[0][lb.ibnd] + gi;
+    lb.m_koff1 = lk.m_koff[1][lb.ibnd] + gi;
     return lb;
 }
 
@@ -639,13 +648,13 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
                          col_dry;
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk)
     FT tau_minor = FT(0);
-    const int n = lb.m_n[tropo];
+    const int n = lb.m_n(tropo);
     if (n > 0) {
-        const FT *kmn = lk.m_kminor[tropo];
-        const unsigned NCb = lk.m_ncontrib[tropo] * E;
-        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.m_koff[tropo] * E;
-        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.m_koff[tropo] * E;
-        const FT *ms = sh.c_mscale + lb.m_st[tropo] * CH + kk;
+        const FT *kmn = tropo ? lk.m_kminor[1] : lk.m_kminor[0];
+        const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
+        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.m_koff(tropo) * E;
+        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.m_koff(tropo) * E;
+        const FT *ms = sh.c_mscale + lb.m_st(tropo) * CH + kk;
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
         // groups of MG intervals: every load of a group is in flight before the first use; slots past
         // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
@@ -673,7 +682,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         ssa = FT(0);
     } else {
         // compute_tau_rayleigh, gas_optics.jl:430-444
-        const FT *rc = lk.rayl[tropo];
+        const FT *rc = tropo ? lk.rayl[1] : lk.rayl[0];
         const unsigned sR = NG * E;
         const unsigned r1 = __umul24(jT * NE + je1, sR) + lb.g * E, r2 = __umul24((jT + 1) * NE + je2, sR) + lb.g * E;
         const FT kr = omfe1 * omfT * ldg<FT>(rc, r1) + fe1 * omfT * ldg<FT>(rc, r1 + sR) + omfe2 * fT * ldg<FT>(rc, r2) +
