@@ -62,6 +62,21 @@ __device__ __forceinline__ float m_sin(float x) { return sinf(x); }
 __device__ __forceinline__ double m_sin(double x) { return sin(x); }
 __device__ __forceinline__ float m_cos(float x) { return cosf(x); }
 __device__ __forceinline__ double m_cos(double x) { return cos(x); }
+// Division and reciprocal of well-scaled Float32 quantities in the per-g-point loops (optical
+// depths, albedos, two-stream denominators: never denormal or near overflow): v_rcp_f32 (1 ulp)
+// times the numerator.  Float64, and -DRR_PRECISE_F32, use the IEEE division.
+__device__ __forceinline__ double m_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double m_div(double a, double b) { return a / b; }
+#ifdef RR_PRECISE_F32
+__device__ __forceinline__ float m_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float m_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float m_sqrt_pos(float x) { return sqrtf(x); }
+#else
+__device__ __forceinline__ float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float m_sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(x); }  // x in [k_min, O(10)]
+#endif
+__device__ __forceinline__ double m_sqrt_pos(double x) { return sqrt(x); }
 template <typename FT> __device__ __forceinline__ FT m_max(FT a, FT b) { return a > b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_min(FT a, FT b) { return a < b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT(0) ? -a : a; }
@@ -364,8 +379,8 @@ template <typename FT>
 __device__ __forceinline__ void increment_2stream(FT &t1, FT &s1, FT &g1, FT t2, FT s2, FT g2) {
     const FT tau = t1 + t2;
     FT ssa = t1 * s1 + t2 * s2;
-    const FT ssag = (t1 * s1 * g1 + t2 * s2 * g2) / m_max(Num<FT>::eps(), ssa);
-    ssa /= m_max(Num<FT>::eps(), tau);
+    const FT ssag = m_div(t1 * s1 * g1 + t2 * s2 * g2, m_max(Num<FT>::eps(), ssa));
+    ssa = m_div(ssa, m_max(Num<FT>::eps(), tau));
     t1 = tau; s1 = ssa; g1 = ssag;
 }
 
@@ -665,7 +680,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
 #pragma unroll
             for (int j = 0; j < MG; j++) {
                 const int i = (i0 + j < n) ? i0 + j : n - 1;
-                const unsigned c = (unsigned)i * cstep;
+                const unsigned c = __umul24((unsigned)i, cstep);
                 c11[j] = ldg<FT>(kmn, a1 + c); c21[j] = ldg<FT>(kmn, a1 + NCb + c);
                 c12[j] = ldg<FT>(kmn, a2 + c); c22[j] = ldg<FT>(kmn, a2 + NCb + c);
                 sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
@@ -689,7 +704,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
                       fe2 * fT * ldg<FT>(rc, r2 + sR);
         const FT tau_ray = kr * (lr.w + FT(1)) * col_dry;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
-        ssa = tau_ray * (FT(1) / tau);
+        ssa = tau_ray * m_rcp(tau);
         if (tau <= FT(0)) ssa = FT(0);
         pfrac = FT(0);
     }

@@ -23,12 +23,12 @@ __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_s
     const FT lw_diff_sec = FT(1.66);
     const FT gamma1 = lw_diff_sec * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
     const FT gamma2 = lw_diff_sec * FT(0.5) * ssa * (FT(1) - g);
-    const FT k = m_sqrt(m_max(lw_diff_sec * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
+    const FT k = m_sqrt_pos(m_max(lw_diff_sec * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
     FT e1, om1;
     exp_pair(tau * k, e1, om1);
     const FT coeff = e1 * e1;
     const FT one_minus_e2kt = om1 * (FT(1) + e1);
-    const FT RT_term = FT(1) / (k * (FT(1) + coeff) + gamma1 * one_minus_e2kt);
+    const FT RT_term = m_rcp(k * (FT(1) + coeff) + gamma1 * one_minus_e2kt);
     Rdif = RT_term * gamma2 * one_minus_e2kt;
     Tdif = RT_term * FT(2) * k * e1;
     if (tau > FT(0)) {
@@ -36,7 +36,7 @@ __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_s
         const FT gamma_sum = gamma1 + gamma2;
         const FT one_p_e1 = FT(1) + e1;
         const FT emis_fac = om1 * (k * om1 + lw_diff_sec * (FT(1) - ssa) * one_p_e1) * RT_term;
-        const FT dBz = dB * (om1 / tau) * (k * om1 + gamma_sum * one_p_e1) * RT_term / m_max(gamma_sum, Num<FT>::eps());
+        const FT dBz = m_div(dB * m_div(om1, tau) * (k * om1 + gamma_sum * one_p_e1) * RT_term, m_max(gamma_sum, Num<FT>::eps()));
         src_up = Num<FT>::pi() * (lev_src_top * emis_fac - Tdif * dB + dBz);
         src_dn = Num<FT>::pi() * (lev_src_bot * emis_fac + Tdif * dB - dBz);
     } else {
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             auto add_layer = [&](int kl, FT lev_src_top) {   // layer kl between levels kl and kl+1
                 FT Rdif, Tdif, src_up, src_dn;
                 lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
-                const FT denom = FT(1) / (FT(1) - Rdif * albedo);  // Eq 10
+                const FT denom = m_rcp(FT(1) - Rdif * albedo);  // Eq 10
                 sw.at(kl, 0) = Tdif * denom;                         // A
                 sw.at(kl, 1) = (Rdif * src + src_dn) * denom;        // B
                 sw.at(kl, 2) = albedo;

@@ -24,25 +24,25 @@ __device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, 
     const FT gamma4 = FT(1) - gamma3;
     const FT alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
     const FT alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-    const FT k = m_sqrt(m_max(FT(2) * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
+    const FT k = m_sqrt_pos(m_max(FT(2) * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
     FT exp_minusktau, om1;
     exp_pair(tau * k, exp_minusktau, om1);
     const FT exp_minus2ktau = exp_minusktau * exp_minusktau;
     const FT one_minus_e2kt = om1 * (FT(1) + exp_minusktau);
-    FT RT_term = FT(1) / (k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
+    FT RT_term = m_rcp(k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
     Rdif = RT_term * gamma2 * one_minus_e2kt;
     Tdif = RT_term * FT(2) * k * exp_minusktau;
-    const FT T0 = m_exp(-tau / m_max(mu0, mu0_min<FT>()));
+    const FT T0 = m_exp(-m_div(tau, m_max(mu0, mu0_min<FT>())));
     FT k_mu = k * mu0;
     FT k_mu2 = k_mu * k_mu;
     const FT diff = FT(1) - k_mu2;
     if (m_abs(diff) < resonance_window<FT>()) {
         k_mu2 = diff >= FT(0) ? FT(1) - resonance_window<FT>() : FT(1) + resonance_window<FT>();
-        k_mu = m_sqrt(k_mu2);
+        k_mu = m_sqrt_pos(k_mu2);
     }
     const FT k_gamma3 = k * gamma3;
     const FT k_gamma4 = k * gamma4;
-    RT_term = ssa * RT_term / (FT(1) - k_mu2);
+    RT_term = m_div(ssa * RT_term, FT(1) - k_mu2);
     const FT Rdir_u = RT_term * ((FT(1) - k_mu) * (alpha2 + k_gamma3) -
                                  (FT(1) + k_mu) * (alpha2 - k_gamma3) * exp_minus2ktau -
                                  FT(2) * (k_gamma3 - alpha2 * k_mu) * exp_minusktau * T0);
@@ -54,7 +54,7 @@ __device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, 
     const FT av_energy = m_max(FT(0), FT(1) - T0);
     const FT tot_dir = Rdir + Tdir;
     if (tot_dir > av_energy) {
-        const FT scale = av_energy / m_max(Num<FT>::eps(), tot_dir);
+        const FT scale = m_div(av_energy, m_max(Num<FT>::eps(), tot_dir));
         Rdir *= scale;
         Tdir *= scale;
     }
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                     FT Rdir, Tdir, Rdif, Tdif;
                     sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
                     const FT s_up = Rdir * dir_above, s_dn = Tdir * dir_above;
-                    const FT den = FT(1) / (FT(1) - beta * Rdif);
+                    const FT den = m_rcp(FT(1) - beta * Rdif);
                     sw.at(k, 0) = Tdif * den;                       // U_{k+1} = A U_k + B
                     sw.at(k, 1) = (Rdif * delta + s_up) * den;
                     sw.at(k, 2) = beta;                             // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             // ---- surface: U_1 = alb_dif D_1 + dir_sfc alb_dir, D_1 = beta_1 U_1 + delta_1 ----
             const FT alb = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
             const FT sfc_src = dir_above * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
-            FT U = (alb * delta + sfc_src) / (FT(1) - alb * beta);
+            FT U = m_div(alb * delta + sfc_src, FT(1) - alb * beta);
             {
                 const FT su = wave_sum_to_lane63(U * amask), sb = wave_sum_to_lane63(beta * U * amask);
                 if (lane == 63) { acc[0] = su; acc[1] = (acc[1] + sb) + acc[2]; }
