@@ -1,0 +1,207 @@
+"""Layer-2 solver aggregate: `RRTMGPSolver`, `update_fluxes`, flux getters.
+
+Host-side mirror of src/api/solver.jl:136-331, src/api/update_fluxes.jl:12-281 and the
+flux/diagnostic getters of src/api/getters.jl (public.jl:64-123): the call order of the
+reference (`prepare_atmosphere!` -> `update_lw_fluxes!` -> `update_sw_fluxes!` ->
+`update_net_fluxes!`), the clear-sky-diagnostic double solve, and the `(nlev, ncol)`
+presentation of every flux.  The device work behind it is the C ABI of
+libhip_rrtmgp.so; nothing here computes fluxes.
+
+Scope: `NoInterpolation` only — level interpolation and the isothermal
+boundary layer (src/api/grid_adaptation.jl, interpolation.jl) are the "next" row N2.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _abi, rte
+from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, RRTMGPParameters, SwBCs, VmrGM,
+                     array_dtype, to_host)
+
+
+# radiation methods, src/api/radiation_methods.jl:19-70
+class GrayRadiation:
+    pass
+
+
+@dataclass
+class ClearSkyRadiation:
+    aerosol_radiation: bool = False
+
+
+@dataclass
+class AllSkyRadiation:
+    aerosol_radiation: bool = False
+    reset_rng_seed: bool = False
+
+
+@dataclass
+class AllSkyRadiationWithClearSkyDiagnostics:
+    aerosol_radiation: bool = False
+    reset_rng_seed: bool = False
+
+
+@dataclass
+class LookupBundle:
+    """Typed bundle of the lookup tables a method needs (src/api/lookup_bundle.jl)."""
+    lookup_lw: object = None
+    lookup_sw: object = None
+    lookup_lw_cld: object = None
+    lookup_sw_cld: object = None
+    lookup_lw_aero: object = None
+    lookup_sw_aero: object = None
+
+
+class RRTMGPSolver:
+    """RRTMGPSolver(grid, method, params, bcs_lw, bcs_sw, as; ...) of src/api/solver.jl:136.
+
+    `op_lw` / `op_sw` are "twostream" (TwoStream) or "onescalar" (OneScalar) and pick the
+    solver exactly as solver.jl:273-310 does.
+    """
+
+    def __init__(self, radiation_method, params: RRTMGPParameters, bcs_lw: LwBCs, bcs_sw: SwBCs, as_,
+                 op_lw: str = "twostream", op_sw: str = "twostream", deep_atmosphere_inverse_scaling=None,
+                 lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0):
+        self.radiation_method, self.params, self.as_ = radiation_method, params, as_
+        self.deep_atmosphere_inverse_scaling = deep_atmosphere_inverse_scaling
+        gray = isinstance(radiation_method, GrayRadiation)
+        # constructor-time errors of solver.jl:159-181
+        if n_gauss_angles != 1:
+            if gray:
+                raise ValueError("`n_gauss_angles` applies only to spectral radiation; gray radiation uses the "
+                                 "single diffusivity angle.")
+            if op_lw != "onescalar":
+                raise ValueError("`n_gauss_angles` applies only to the non-scattering longwave solver; pass "
+                                 "op_lw='onescalar'.")
+        if op_sw == "onescalar" and not gray:
+            raise ValueError("non-scattering shortwave optics are only supported with GrayRadiation; spectral "
+                             "shortwave radiation requires scattering.")
+        if not gray and lookups is None:
+            raise ValueError("spectral radiation needs `lookups` (the NetCDF loader is outside this back end)")
+        self.lookups = lookups or LookupBundle()
+        nlay, ncol = as_.dims
+        dtype = as_.dtype
+        self.nlay, self.ncol, self.dtype = nlay, ncol, dtype
+        ws = rte.Workspace(ncol, nlay, dtype, device)  # LW and SW share the library scratch
+        lw_cls = rte.TwoStreamLWRTE if op_lw == "twostream" else rte.NoScatLWRTE
+        sw_cls = rte.TwoStreamSWRTE if op_sw == "twostream" else rte.NoScatSWRTE
+        # compute buffers ARE the (nlev, ncol) presentation: update_presentation! is a no-op here
+        self.lws = lw_cls(ncol, nlay, dtype, bcs_lw, n_gauss_angles=n_gauss_angles, workspace=ws)
+        self.sws = sw_cls(ncol, nlay, dtype, bcs_sw, workspace=ws)
+        self.net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F")
+        diag = isinstance(radiation_method, AllSkyRadiationWithClearSkyDiagnostics)
+        self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False) if diag else None
+        self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True) if diag else None
+        self.clear_net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F") if diag else None
+        self._seed = 0
+
+    # ---- prepare_atmosphere!, update_fluxes.jl:252-281 (NoInterpolation) ----------------------
+    def prepare_atmosphere(self):
+        as_ = self.as_
+        if isinstance(as_, GrayAtmosphericState):
+            return  # gray: p_min clip only applies with lookup tables (get_p_min -> 0 for gray)
+        lw = self.lookups.lookup_lw
+        p_min, t_min, t_max = lw.p_ref_min, lw.t_ref_min, lw.t_ref_max
+        ft = as_.dtype.type
+        # clip!, grid_adaptation.jl:232-258
+        h2o = as_.vmr.vmr_h2o if isinstance(as_.vmr, VmrGM) else as_.vmr.vmr[lw.idx_h2o - 1]
+        np.maximum(h2o, ft(0), out=h2o)
+        np.maximum(as_.layerdata[1], ft(p_min), out=as_.layerdata[1])
+        np.maximum(as_.p_lev, ft(p_min), out=as_.p_lev)
+        np.clip(as_.layerdata[2], ft(t_min), ft(t_max), out=as_.layerdata[2])
+        np.clip(as_.t_lev, ft(t_min), ft(t_max), out=as_.t_lev)
+        # update_concentrations! -> compute_col_gas!(device, ...), grid_adaptation.jl:278-292
+        col_dry = rte.compute_col_gas(self.lws.ws, as_.p_lev, self.params, np.asfortranarray(h2o), as_.lat)
+        as_.layerdata[0] = col_dry
+
+    # ---- update_lw_fluxes!, update_fluxes.jl:12-65 ------------------------------------------------
+    def update_lw_fluxes(self):
+        m, lk, ms = self.radiation_method, self.lookups, self.deep_atmosphere_inverse_scaling
+        if isinstance(m, GrayRadiation):
+            rte.solve_lw(self.lws, self.as_, metric_scaling=ms)
+            return
+        aero = lk.lookup_lw_aero if m.aerosol_radiation else None
+        if isinstance(m, ClearSkyRadiation):
+            rte.solve_lw(self.lws, self.as_, lk.lookup_lw, None, aero, ms, seed=self._seed)
+        elif isinstance(m, AllSkyRadiation):
+            rte.solve_lw(self.lws, self.as_, lk.lookup_lw, lk.lookup_lw_cld, aero, ms, seed=self._seed)
+        else:
+            rte.solve_lw(self.lws, self.as_, lk.lookup_lw, None, aero, ms, seed=self._seed)
+            for n in ("flux_up", "flux_dn", "flux_net"):
+                getattr(self.clear_flux_lw, n)[...] = getattr(self.lws.flux, n)
+            rte.solve_lw(self.lws, self.as_, lk.lookup_lw, lk.lookup_lw_cld, aero, ms, seed=self._seed)
+
+    # ---- update_sw_fluxes!, update_fluxes.jl:74-128 -----------------------------------------------
+    def update_sw_fluxes(self):
+        m, lk, ms = self.radiation_method, self.lookups, self.deep_atmosphere_inverse_scaling
+        if isinstance(m, GrayRadiation):
+            rte.solve_sw(self.sws, self.as_, metric_scaling=ms)
+            return
+        aero = lk.lookup_sw_aero if m.aerosol_radiation else None
+        if isinstance(m, ClearSkyRadiation):
+            rte.solve_sw(self.sws, self.as_, lk.lookup_sw, None, aero, ms, seed=self._seed)
+        elif isinstance(m, AllSkyRadiation):
+            rte.solve_sw(self.sws, self.as_, lk.lookup_sw, lk.lookup_sw_cld, aero, ms, seed=self._seed)
+        else:
+            rte.solve_sw(self.sws, self.as_, lk.lookup_sw, None, aero, ms, seed=self._seed)
+            for n in ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"):
+                getattr(self.clear_flux_sw, n)[...] = getattr(self.sws.flux, n)
+            rte.solve_sw(self.sws, self.as_, lk.lookup_sw, lk.lookup_sw_cld, aero, ms, seed=self._seed)
+
+    # ---- update_net_fluxes!, update_fluxes.jl:165-194 ----------------------------------------------
+    def update_net_fluxes(self):
+        np.add(self.lws.flux.flux_net, self.sws.flux.flux_net, out=self.net_flux_buffer)
+        if self.clear_net_flux_buffer is not None:
+            np.add(self.clear_flux_lw.flux_net, self.clear_flux_sw.flux_net, out=self.clear_net_flux_buffer)
+
+    # ---- update_fluxes!, update_fluxes.jl:223-233 ----------------------------------------------------
+    def update_fluxes(self, seedval=None):
+        m = self.radiation_method
+        # _maybe_reset_rng_seed!: here the seed keys the counter-based McICA stream
+        if getattr(m, "reset_rng_seed", False) and seedval is not None:
+            self._seed = int(seedval)
+        self.prepare_atmosphere()
+        self.update_lw_fluxes()
+        self.update_sw_fluxes()
+        self.update_net_fluxes()
+
+
+def update_fluxes(s: RRTMGPSolver, seedval=None):
+    s.update_fluxes(seedval)
+
+
+# ---- getters (src/api/getters.jl; names of public.jl:96-118) ----------------------------------------
+def lw_flux_up(s): return s.lws.flux.flux_up
+def lw_flux_dn(s): return s.lws.flux.flux_dn
+def lw_flux_net(s): return s.lws.flux.flux_net
+def sw_flux_up(s): return s.sws.flux.flux_up
+def sw_flux_dn(s): return s.sws.flux.flux_dn
+def sw_flux_net(s): return s.sws.flux.flux_net
+def sw_direct_flux_dn(s): return s.sws.flux.flux_dn_dir
+def net_flux(s): return s.net_flux_buffer
+def clear_lw_flux_up(s): return s.clear_flux_lw.flux_up
+def clear_lw_flux_dn(s): return s.clear_flux_lw.flux_dn
+def clear_lw_flux_net(s): return s.clear_flux_lw.flux_net
+def clear_sw_flux_up(s): return s.clear_flux_sw.flux_up
+def clear_sw_flux_dn(s): return s.clear_flux_sw.flux_dn
+def clear_sw_direct_flux_dn(s): return s.clear_flux_sw.flux_dn_dir
+def clear_sw_flux_net(s): return s.clear_flux_sw.flux_net
+def clear_net_flux(s): return s.clear_net_flux_buffer
+def lw_cloud_cover(s): return s.as_.cloud_state.cld_cover_lw
+def sw_cloud_cover(s): return s.as_.cloud_state.cld_cover_sw
+def aod_sw_extinction(s): return s.as_.aerosol_state.aod_sw_ext
+def aod_sw_scattering(s): return s.as_.aerosol_state.aod_sw_sca
+def level_pressure(s): return s.as_.p_lev
+def layer_pressure(s): return s.as_.p_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[1]
+def layer_temperature(s): return s.as_.t_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[2]
+def level_temperature(s): return s.as_.t_lev
+def surface_temperature(s): return s.as_.t_sfc
+
+
+def heating_rate(s: RRTMGPSolver):
+    """heating_rate (src/api/standalone.jl:100-122): (g / cp) dF_net/dp per layer [K/s]; fresh array."""
+    nf, p = net_flux(s), to_host(level_pressure(s))
+    return np.asfortranarray(s.params.grav * (nf[1:] - nf[:-1]) / (p[1:] - p[:-1]) / s.params.cp_d).astype(s.dtype)

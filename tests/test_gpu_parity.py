@@ -273,3 +273,79 @@ def test_full_size_properties(tables32):
     sub = S.make_columns(1, nlay, np.float32, seed=2026, aerosols=True, night_fraction=0.1, col_offset=int(idx[3]))
     ref = O.solve_lw(sub[0], sub[1], t["lw"], t["cld_lw"], t["aero_lw"], col_offset=int(idx[3]))
     assert np.abs(ref.flux_up[:, 0] - lw.flux_up[:, idx[3]]).max() < 1e-3
+
+
+# ---- Layer-2 aggregate: RRTMGPSolver / update_fluxes / getters -----------------------------------
+def test_rrtmgp_solver_update_fluxes_with_clear_sky_diagnostics(tables64):
+    """update_fluxes! call order and the clear-sky-diagnostic double solve (update_fluxes.jl:39-65,
+    101-128,165-194,223-233); net = lw + sw (test/standalone.jl:30); clear OLR >= all-sky OLR
+    (all_sky_with_aerosols_utils.jl:190-197); heating rate == flux divergence (api_contract.jl:307-320)."""
+    import copy
+    from rrtmgp_jl_amd import solver as L2
+    from rrtmgp_jl_amd.states import TEST_PARAMETERS
+    t = tables64
+    as_, lb, sb = S.make_columns(9, 32, np.float64, seed=17, aerosols=True, night_fraction=0.2, random_cld_frac=True)
+    as_.vmr.vmr_h2o[3, 2] = -1e-4       # clip!: vmr_h2o >= 0
+    as_.layerdata[2][5, 1] = 400.0      # clip!: T within the lookup range
+    as_.t_lev[0, 4] = 120.0
+    ref_as = copy.deepcopy(as_)
+    lookups = L2.LookupBundle(t["lw"], t["sw"], t["cld_lw"], t["cld_sw"], t["aero_lw"], t["aero_sw"])
+    s = L2.RRTMGPSolver(L2.AllSkyRadiationWithClearSkyDiagnostics(aerosol_radiation=True, reset_rng_seed=True),
+                        TEST_PARAMETERS, lb, sb, as_, lookups=lookups)
+    L2.update_fluxes(s, 42)
+    # reference: the same preparation restated with numpy + the oracle, then the oracle solves
+    lw = t["lw"]
+    h2o = ref_as.vmr.vmr_h2o
+    np.maximum(h2o, 0.0, out=h2o)
+    np.maximum(ref_as.layerdata[1], lw.p_ref_min, out=ref_as.layerdata[1])
+    np.maximum(ref_as.p_lev, lw.p_ref_min, out=ref_as.p_lev)
+    np.clip(ref_as.layerdata[2], lw.t_ref_min, lw.t_ref_max, out=ref_as.layerdata[2])
+    np.clip(ref_as.t_lev, lw.t_ref_min, lw.t_ref_max, out=ref_as.t_lev)
+    ref_as.layerdata[0] = O.compute_col_gas(ref_as.p_lev, TEST_PARAMETERS, h2o, ref_as.lat)
+    np.testing.assert_allclose(as_.layerdata[0], ref_as.layerdata[0], rtol=1e-13)
+    r_lw = O.solve_lw(ref_as, lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=42)
+    r_sw = O.solve_sw(ref_as, sb, t["sw"], t["cld_sw"], t["aero_sw"], seed=42)
+    c_lw = O.solve_lw(ref_as, lb, t["lw"], None, t["aero_lw"], seed=42)
+    c_sw = O.solve_sw(ref_as, sb, t["sw"], None, t["aero_sw"], seed=42)
+    tol = 1e-8
+    assert np.abs(L2.lw_flux_up(s) - r_lw.flux_up).max() < tol and np.abs(L2.lw_flux_dn(s) - r_lw.flux_dn).max() < tol
+    assert np.abs(L2.sw_flux_up(s) - r_sw.flux_up).max() < tol and np.abs(L2.sw_flux_dn(s) - r_sw.flux_dn).max() < tol
+    assert np.abs(L2.sw_direct_flux_dn(s) - r_sw.flux_dn_dir).max() < tol
+    assert np.abs(L2.clear_lw_flux_up(s) - c_lw.flux_up).max() < tol
+    assert np.abs(L2.clear_sw_flux_dn(s) - c_sw.flux_dn).max() < tol
+    np.testing.assert_array_equal(L2.net_flux(s), L2.lw_flux_net(s) + L2.sw_flux_net(s))
+    np.testing.assert_array_equal(L2.clear_net_flux(s), L2.clear_lw_flux_net(s) + L2.clear_sw_flux_net(s))
+    assert np.all(L2.clear_lw_flux_up(s)[-1] >= L2.lw_flux_up(s)[-1] - 1e-9)
+    cov = L2.lw_cloud_cover(s)
+    assert np.all((cov >= 0) & (cov <= 1))
+    assert np.all(L2.aod_sw_extinction(s) >= L2.aod_sw_scattering(s))
+    hr = L2.heating_rate(s)
+    p, nf = L2.level_pressure(s), L2.net_flux(s)
+    np.testing.assert_allclose(hr, TEST_PARAMETERS.grav * (nf[1:] - nf[:-1]) / (p[1:] - p[:-1]) / TEST_PARAMETERS.cp_d,
+                               rtol=1e-12)
+    # second call with the same seed reproduces the fluxes bit for bit; another seed changes them
+    up1 = L2.lw_flux_up(s).copy()
+    L2.update_fluxes(s, 42)
+    np.testing.assert_array_equal(L2.lw_flux_up(s), up1)
+    L2.update_fluxes(s, 43)
+    assert np.any(L2.lw_flux_up(s) != up1)
+
+
+def test_rrtmgp_solver_gray_and_constructor_errors():
+    from rrtmgp_jl_amd import solver as L2
+    params = RRTMGPParameters()
+    ncol, nlay = 5, 30
+    gs = O.setup_gray_as_pr_grid(nlay, np.linspace(-60.0, 60.0, ncol), 100000.0, 9000.0,
+                                 GrayOpticalThicknessOGorman2008(), params, np.float64)
+    lb = LwBCs(np.ones((1, ncol), order="F"), None)
+    sb = SwBCs(np.full(ncol, 0.6), np.full(ncol, 1360.0), np.full((1, ncol), 0.1, order="F"),
+               np.full((1, ncol), 0.1, order="F"))
+    s = L2.RRTMGPSolver(L2.GrayRadiation(), params, lb, sb, gs)
+    L2.update_fluxes(s)
+    assert np.abs(L2.lw_flux_up(s) - O.solve_lw_gray(gs, lb).flux_up).max() < 1e-9
+    assert np.abs(L2.sw_flux_dn(s) - O.solve_sw_gray(gs, sb).flux_dn).max() < 1e-9
+    np.testing.assert_array_equal(L2.net_flux(s), L2.lw_flux_net(s) + L2.sw_flux_net(s))
+    with pytest.raises(ValueError):
+        L2.RRTMGPSolver(L2.GrayRadiation(), params, lb, sb, gs, n_gauss_angles=2)
+    with pytest.raises(ValueError):
+        L2.RRTMGPSolver(L2.ClearSkyRadiation(), params, lb, sb, gs, op_sw="onescalar", lookups=L2.LookupBundle())

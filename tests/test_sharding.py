@@ -1,0 +1,88 @@
+"""Multi-GPU path on CPU: one process per rank over `gloo`, world_size 2.
+
+Columns shard embarrassingly; what has to be right is the sharding and
+gather plumbing and that a column's result does not depend on how columns are split
+(the McICA stream is keyed by the GLOBAL column index).  The compute function injected
+here is the CPU oracle (allowed in tests only); on GPUs it is the HIP solve.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from rrtmgp_jl_amd import sharding, synthetic as S
+
+
+def test_shard_ranges_cover_and_balance():
+    for ncol, world in [(10, 3), (7, 8), (4096, 8), (1, 2), (131072 * 8, 8)]:
+        rs = [sharding.shard_range(ncol, r, world) for r in range(world)]
+        assert rs[0][0] == 0 and rs[-1][1] == ncol
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+        w = [hi - lo for lo, hi in rs]
+        assert max(w) - min(w) <= 1
+
+
+def test_shard_container_slices_every_column_array():
+    as_, lb, sb = S.make_columns(19, 6, np.float64, seed=3, aerosols=True, inc_flux_ngpt=24, n_bnd_lw=3, n_bnd_sw=3)
+    sh = sharding.shard_container(as_, 5, 12, 19)
+    assert sh.dims == (6, 7)
+    np.testing.assert_array_equal(sh.layerdata, as_.layerdata[:, :, 5:12])
+    np.testing.assert_array_equal(sh.vmr.vmr_h2o, as_.vmr.vmr_h2o[:, 5:12])
+    assert sh.vmr.vmr.shape == as_.vmr.vmr.shape  # well-mixed vector (length 19 == ncol here) is NOT sliced
+    np.testing.assert_array_equal(sh.cloud_state.cld_frac, as_.cloud_state.cld_frac[:, 5:12])
+    np.testing.assert_array_equal(sh.aerosol_state.aero_mass, as_.aerosol_state.aero_mass[:, :, 5:12])
+    assert sh.t_sfc.shape == (7,) and sh.lat.shape == (7,)
+    lbs = sharding.shard_container(lb, 5, 12, 19)
+    np.testing.assert_array_equal(lbs.inc_flux, lb.inc_flux[5:12])  # (ncol, ngpt): column index first
+    np.testing.assert_array_equal(lbs.sfc_emis, lb.sfc_emis[:, 5:12])
+    sbs = sharding.shard_container(sb, 5, 12, 19)
+    assert sbs.cos_zenith.shape == (7,) and sbs.sfc_alb_direct.shape == (3, 7)
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        ncol, nlay = 11, 12
+        lw = S.make_gas_lookup("lw", np.float64, seed=7, n_bnd=3, gpt_per_bnd=[8, 4, 12])
+        sw = S.make_gas_lookup("sw", np.float64, seed=7, n_bnd=3, gpt_per_bnd=[6, 10, 4])
+        cl, cs = S.make_cloud_lookup("lw", 3, seed=7), S.make_cloud_lookup("sw", 3, seed=7)
+        as_, lb, sb = S.make_columns(ncol, nlay, np.float64, seed=5, random_cld_frac=True, n_bnd_lw=3, n_bnd_sw=3,
+                                     night_fraction=0.2)
+        f_lw, (lo, hi) = sharding.solve_sharded(lambda a, b, col_offset: O.solve_lw(a, b, lw, cl, seed=9, col_offset=col_offset),
+                                                as_, lb, ncol, rank, world)
+        f_sw, _ = sharding.solve_sharded(lambda a, b, col_offset: O.solve_sw(a, b, sw, cs, seed=9, col_offset=col_offset),
+                                         as_, sb, ncol, rank, world)
+        assert f_lw.flux_up.shape == (nlay + 1, hi - lo)
+        g_lw = sharding.gather_columns(f_lw.flux_up, ncol)
+        g_sw = sharding.gather_columns(f_sw.flux_dn, ncol)
+        ref_lw = O.solve_lw(as_, lb, lw, cl, seed=9).flux_up
+        ref_sw = O.solve_sw(as_, sb, sw, cs, seed=9).flux_dn
+        ok = bool(np.array_equal(g_lw, ref_lw) and np.array_equal(g_sw, ref_sw))
+        # timing agreement used by bench.py: MAX over ranks
+        import torch
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ok, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_matches_unsharded():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 2.0), (1, True, 2.0)]
