@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--aerosols", action="store_true")
     ap.add_argument("--cld-frac", type=float, default=1.0, help="cloud fraction of cloudy layers (reference benchmark: 1)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="columns for the CPU baseline (0 disables)")
+    ap.add_argument("--host", action="store_true",
+                    help="hand HOST arrays to the C ABI (library stages H2D/D2H every step): the PCIe-inclusive rate "
+                         "quoted in DESIGN.md, never the headline value")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1: LW and SW kernels on torch's current stream; 2: each on its own stream (concurrent)")
     args = ap.parse_args()
@@ -85,9 +88,12 @@ def main():
     col_offset = rank * ncol
     as_h, lb_h, sb_h = S.make_columns(ncol, nlay, ft, seed=2026, col_offset=col_offset, clouds=True,
                                       cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
-    as_d, lb_d, sb_d = as_h.to_device(dev), lb_h.to_device(dev), sb_h.to_device(dev)
-    slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=dev)
-    slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=dev)
+    if args.host:
+        as_d, lb_d, sb_d = as_h, lb_h, sb_h
+    else:
+        as_d, lb_d, sb_d = as_h.to_device(dev), lb_h.to_device(dev), sb_h.to_device(dev)
+    slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev)
+    slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=None if args.host else dev)
     if args.streams == 1:
         slv_lw.ws.use_torch_stream()
         slv_sw.ws.use_torch_stream()
@@ -121,10 +127,11 @@ def main():
         elapsed = float(t.item())
 
     # sanity: results are finite and physical (never timed)
-    if not os.environ.get("RRTMGP_HIP_ABLATE"):  # (debug ablation runs produce garbage by design)
-        up = slv_lw.flux.flux_up
-        assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
-        assert bool(torch.isfinite(slv_sw.flux.flux_dn).all())
+    up, sdn = torch.as_tensor(slv_lw.flux.flux_up), torch.as_tensor(slv_sw.flux.flux_dn)
+    if args.host:
+        up, sdn = up.T, sdn.T  # numpy (nlev, ncol) -> (ncol, nlev) like the device tensors
+    assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
+    assert bool(torch.isfinite(sdn).all())
 
     if rank == 0:
         ms_lw, ms_sw = k_lw / args.steps, k_sw / args.steps
@@ -139,6 +146,17 @@ def main():
         achieved = dom_bytes * ncol / (dom_ms * 1e-3) / 1e9
         flops = nlay * (lw.n_gpt * LW_FLOPS_PER_CELL + sw.n_gpt * SW_FLOPS_PER_CELL) * ncol
         valu_tflops = flops / ((ms_lw + ms_sw) * 1e-3) / 1e12
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "latest.json")
+        if os.path.exists(prof) and not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32":
+            # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
+            # (tools/profile.sh -> tools/rocprof_summary.py): (2 * FETCH_SIZE + WRITE_SIZE) KB, the factor 2
+            # being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md
+            with open(prof) as fh:
+                pj = json.load(fh)
+            k = pj.get("kernels", {}).get("lw_solve_kernel" if ms_lw >= ms_sw else "sw_solve_kernel")
+            if k and k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
+                traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
         out = {
             "metric": "columns/sec, all-sky LW+SW 2-stream (nlay=64, 256+224 gpt)",
             "value": world * ncol * args.steps / elapsed,
@@ -149,11 +167,12 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"all-sky (McICA clouds, cld_frac={args.cld_frac:g}) LW+SW two-stream, "
                                    f"{ncol} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
-                                   f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, state resident in HBM",
+                                   f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, "
+                                   f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}",
                        "ncol_per_gpu": ncol, "nlay": nlay, "ngpt_lw": lw.n_gpt, "ngpt_sw": sw.n_gpt,
                        "parallelism": f"columns sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_column": dom_bytes, "kernel_ms": dom_ms,
                          "note": "path is FP32-VALU/transcendental + table-gather bound, not HBM bound (SURVEY F8)"},
             "valu": {"achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

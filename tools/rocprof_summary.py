@@ -18,6 +18,27 @@ def q(dbp, sql):
         db.close()
 
 
+def to_json(root, path):
+    """Per-kernel averages (duration in us, PMC counters per launch) as JSON for bench.py's `traffic`."""
+    import json
+    out = {"source": root, "kernels": {}}
+    tr = os.path.join(root, "trace", "bench_results.db")
+    if os.path.exists(tr):
+        for name, calls, tot, avg, pct in q(tr, "select name, total_calls, total_duration, average, percentage from top_kernels"):
+            for key in ("lw_solve_kernel", "sw_solve_kernel"):
+                if key in name:
+                    out["kernels"].setdefault(key, {})["avg_us"] = avg
+                    out["kernels"][key]["calls"] = calls
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*", "bench_results.db"))):
+        for k, c, s, n in q(d, "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
+                               "where kernel_name like '%solve_kernel%' group by kernel_name, counter_name"):
+            for key in ("lw_solve_kernel", "sw_solve_kernel"):
+                if key in k:
+                    out["kernels"].setdefault(key, {})[c] = s / n
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
 def main(root):
     print(f"# rocprofv3 summary of {root}")
     tr = os.path.join(root, "trace", "bench_results.db")
@@ -38,3 +59,5 @@ def main(root):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        to_json(sys.argv[1], sys.argv[2])
