@@ -195,8 +195,8 @@ def main():
                 O.solve_lw(cas, clb, lw, cl, al, seed=2026)
                 O.solve_sw(cas, csb, sw, cs, asw, seed=2026)
                 return time.perf_counter() - tc
-            probe = cpu_run(64)                                  # sizes the sample to ~15 s of CPU work
-            n = int(min(max(64, sample if args.cpu_sample else 15.0 * 64 / probe), 16384, ncol))
+            probe = cpu_run(1024)                                # sizes the sample to ~15 s of CPU work
+            n = int(min(max(1024, sample if args.cpu_sample else 15.0 * 1024 / probe), 65536, ncol))
             tc = cpu_run(n)
             out["cpu_baseline"] = {"value": n / tc, "unit": "columns/s", "cores": min(O.n_threads(), 32), "kind": "port",
                                    "sample": f"{n} columns of the same workload, oracle/rrtmgp_oracle.c "
