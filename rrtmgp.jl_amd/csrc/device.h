@@ -168,74 +168,67 @@ struct alignas(4 * sizeof(FT)) V4 {
     FT x, y, z, w;
 };
 
+constexpr int NBMAX = 16;  // bands per lookup the chunk records are laid out for (v1.9: 16 LW / 14 SW)
+
+// Everything the kernels keep per layer, one record per layer (array of structs: a single LDS
+// base address, constant field offsets).
+template <typename FT>
+struct alignas(32) LayerRec {
+    FT fT, fP, col_dry, h2o;   // read together by the g-point lanes (one ds_read_b128 in Float32)
+    int idx;                   // jT | jP << 8 | tropo << 16 (0-based lower T index, lower p plane, 0 = lower atm.)
+    int aero_mask;
+    int liq_loc, ice_loc;
+    FT dens_fact, dry_fact, cld_frac, path_liq;
+    FT path_ice, liq_fac, ice_fac, rh_f;
+    int rh_loc, pl_lay_loc;
+    FT pl_lay_f, aod_t, aod_ts;  // aod_*: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
+};
+template <typename FT>
+struct LevelRec {
+    FT f;     // Planck-table position of t_lev (LW)
+    int loc;
+};
+
+// Band-level records of one chunk of CH layers, fixed strides (record r = kk * NBMAX + band), so every
+// array sits at a compile-time LDS offset.
+template <typename FT>
+struct alignas(32) ChunkFixed {
+    V4<FT> eta[CH * NBMAX];  // fe1, fe2, cm1, cm2
+    V4<FT> cld[CH * NBMAX];  // cloud (tau, ssa, g, -) or (absorption tau, -, -, -)
+    V4<FT> aer[CH * NBMAX];
+    FT Blev[(CH + 1) * NBMAX];
+    FT Blay[CH * NBMAX];
+    int je[CH * NBMAX];      // je1 | je2 << 8
+};
+
 template <typename FT>
 struct ColShared {
-    // ---- whole column, written by prepare_column --------------------------------------
-    FT *vmr;          // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
-    V4<FT> *lay;      // [nlay]: fT, fP, col_dry, vmr_h2o
-    int *lay_idx;     // jT | jP << 8 | tropo << 16  (0-based lower T index, lower p plane, 0 = lower atmosphere)
-    FT *dens_fact, *dry_fact;
-    int *pl_lev_loc, *pl_lay_loc;
-    FT *pl_lev_f, *pl_lay_f;
-    FT *cld_frac, *path_liq, *path_ice, *liq_fac, *ice_fac;
-    int *liq_loc, *ice_loc;
-    int *rh_loc;
-    FT *rh_f;
-    unsigned char *aero_mask;
-    FT *aod_lay;  // [2][nlay]: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
-    // ---- one chunk of CH layers, written by prepare_chunk --------------------------------
-    int *c_je;        // [CH][nbnd]: je1 | je2 << 8
-    V4<FT> *c_eta;    // [CH][nbnd]: fe1, fe2, cm1, cm2
-    FT *c_mscale;     // [max_int][CH]
-    FT *c_Blev;       // [(CH+1)][nbnd]   (LW)
-    FT *c_Blay;       // [CH][nbnd]       (LW)
-    V4<FT> *c_cld;    // [CH][nbnd]: cloud (tau, ssa, g, -) or (absorption tau, -, -, -)
-    V4<FT> *c_aer;    // [CH][nbnd]
-    // ---- accumulators -----------------------------------------------------------------------
-    FT *acc;    // [nwaves][nlev][n_acc]
-    int *misc;  // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
-    FT *miscf;  // [0]: pl_sfc_f
+    ChunkFixed<FT> *ch;  // LDS offset 0
+    LayerRec<FT> *lay;   // constant offset
+    LevelRec<FT> *lev;   // [nlev]
+    FT *vmr;             // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
+    FT *mscale;          // [max_int][CH] minor-gas scalings of the current chunk
+    FT *acc;             // [nwaves][nlev][n_acc]
+    int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
+    FT *miscf;           // [0]: pl_sfc_f
 };
 
 template <typename T>
 __host__ __device__ inline T *carve(char *&p, size_t n) {
     T *r = reinterpret_cast<T *>(p);
-    p += (n * sizeof(T) + 15) & ~size_t(15);
+    p += (n * sizeof(T) + 31) & ~size_t(31);
     return r;
 }
 
 template <typename FT>
 __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
     char *p = base;
-    const int nlay = d.nlay, nlev = d.nlev, nb = d.nbnd;
-    s.lay = carve<V4<FT>>(p, nlay);
-    s.c_eta = carve<V4<FT>>(p, (size_t)CH * nb);
-    if (d.has_cld) s.c_cld = carve<V4<FT>>(p, (size_t)CH * nb);
-    if (d.has_aero) s.c_aer = carve<V4<FT>>(p, (size_t)CH * nb);
-    s.vmr = carve<FT>(p, (size_t)d.ngas1 * nlay);
-    s.dens_fact = carve<FT>(p, nlay); s.dry_fact = carve<FT>(p, nlay);
-    s.lay_idx = carve<int>(p, nlay);
-    if (d.lw) {
-        s.pl_lev_loc = carve<int>(p, nlev); s.pl_lev_f = carve<FT>(p, nlev);
-        s.pl_lay_loc = carve<int>(p, nlay); s.pl_lay_f = carve<FT>(p, nlay);
-    }
-    if (d.has_cld) {
-        s.cld_frac = carve<FT>(p, nlay); s.path_liq = carve<FT>(p, nlay); s.path_ice = carve<FT>(p, nlay);
-        s.liq_fac = carve<FT>(p, nlay); s.ice_fac = carve<FT>(p, nlay);
-        s.liq_loc = carve<int>(p, nlay); s.ice_loc = carve<int>(p, nlay);
-    }
-    if (d.has_aero) {
-        s.rh_loc = carve<int>(p, nlay); s.rh_f = carve<FT>(p, nlay);
-        s.aero_mask = carve<unsigned char>(p, nlay);
-        s.aod_lay = carve<FT>(p, (size_t)2 * nlay);
-    }
-    s.c_je = carve<int>(p, (size_t)CH * nb);
-    s.c_mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
-    if (d.lw) {
-        s.c_Blev = carve<FT>(p, (size_t)(CH + 1) * nb);
-        s.c_Blay = carve<FT>(p, (size_t)CH * nb);
-    }
-    s.acc = carve<FT>(p, (size_t)d.nwaves * nlev * d.n_acc);
+    s.ch = carve<ChunkFixed<FT>>(p, 1);
+    s.lay = carve<LayerRec<FT>>(p, d.nlay);
+    s.lev = carve<LevelRec<FT>>(p, d.nlev);
+    s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
+    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
+    s.acc = carve<FT>(p, (size_t)d.nwaves * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
     return (size_t)(p - base);
@@ -295,13 +288,13 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
     for (int k = tid; k < nlay; k += nt) {
         const FT col_dry = ld[4 * k + 0], p = ld[4 * k + 1], t = ld[4 * k + 2];
-        V4<FT> rec;
-        rec.z = col_dry;
+        LayerRec<FT> rec;
+        rec.col_dry = col_dry;
         const int tropo = p > lk.p_ref_tropo ? 0 : 1;  // gas_optics.jl:188 (0 = lower)
         // compute_interp_frac_temp, gas_optics.jl:87-93
         const FT dT = lk.t_ref[1] - lk.t_ref[0];
         const int jT = loc_lower_eq0(t, dT, lk.n_t_ref, lk.t_ref);
-        rec.x = (t - lk.t_ref[jT]) / dT;
+        rec.fT = (t - lk.t_ref[jT]) / dT;
         // compute_interp_frac_press, gas_optics.jl:100-117
         const FT dlp = lk.ln_p_ref[0] - lk.ln_p_ref[1];
         const FT logp = m_log(p);
@@ -310,34 +303,39 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         j = j < 1 ? 1 : j;
         j = j > n_p_ref - 1 ? n_p_ref - 1 : j;
         j += 1;                                          // 1-based jpress
-        rec.y = (lk.ln_p_ref[j - 2] - logp) / dlp;
+        rec.fP = (lk.ln_p_ref[j - 2] - logp) / dlp;
         const int jP = (j + tropo) - 2;                  // (jpress + tropo1 - 1) - 1 -> 0-based lower plane
-        sh.lay_idx[k] = jT | (jP << 8) | (tropo << 16);
+        rec.idx = jT | (jP << 8) | (tropo << 16);
         {   // vmr_h2o of this layer (get_vmr, VolumeMixingRatios.jl:91-129)
             const int ig = lk.idx_h2o;
             if (as.vmr_kind == RRTMGP_VMR_GM)
-                rec.w = ig == 1 ? as.vmr_h2o[(size_t)nlay * col + k] : ig == 3 ? as.vmr_o3[(size_t)nlay * col + k] : as.vmr[ig - 1];
+                rec.h2o = ig == 1 ? as.vmr_h2o[(size_t)nlay * col + k] : ig == 3 ? as.vmr_o3[(size_t)nlay * col + k] : as.vmr[ig - 1];
             else
-                rec.w = as.vmr[(size_t)(ig - 1) + (size_t)as.ngas * ((size_t)k + (size_t)nlay * col)];
+                rec.h2o = as.vmr[(size_t)(ig - 1) + (size_t)as.ngas * ((size_t)k + (size_t)nlay * col)];
         }
-        sh.lay[k] = rec;
-        sh.dens_fact[k] = FT(0.01) * p / t;              // gas_optics.jl:368-370
-        if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, sh.pl_lay_loc[k], sh.pl_lay_f[k]);
+        rec.dens_fact = FT(0.01) * p / t;                // gas_optics.jl:368-370
+        rec.dry_fact = FT(1) / (FT(1) + rec.h2o);        // gas_optics.jl:367
+        rec.pl_lay_loc = 0; rec.pl_lay_f = FT(0);
+        if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, rec.pl_lay_loc, rec.pl_lay_f);
+        rec.cld_frac = rec.path_liq = rec.path_ice = rec.liq_fac = rec.ice_fac = FT(0);
+        rec.liq_loc = rec.ice_loc = 0;
         if (d.has_cld) {
             const size_t o = (size_t)nlay * col + k;
-            sh.cld_frac[k] = as.cld_frac[o];
-            sh.path_liq[k] = as.cld_path_liq[o];
-            sh.path_ice[k] = as.cld_path_ice[o];
-            cld_pos(as.cld_r_eff_liq[o], cld->radliq_lwr, cld->radliq_upr, cld->nsize_liq, sh.liq_loc[k], sh.liq_fac[k]);
-            cld_pos(as.cld_r_eff_ice[o], cld->radice_lwr, cld->radice_upr, cld->nsize_ice, sh.ice_loc[k], sh.ice_fac[k]);
+            rec.cld_frac = as.cld_frac[o];
+            rec.path_liq = as.cld_path_liq[o];
+            rec.path_ice = as.cld_path_ice[o];
+            cld_pos(as.cld_r_eff_liq[o], cld->radliq_lwr, cld->radliq_upr, cld->nsize_liq, rec.liq_loc, rec.liq_fac);
+            cld_pos(as.cld_r_eff_ice[o], cld->radice_lwr, cld->radice_upr, cld->nsize_ice, rec.ice_loc, rec.ice_fac);
         }
+        rec.aero_mask = 0; rec.rh_loc = 0; rec.rh_f = FT(0); rec.aod_t = rec.aod_ts = FT(0);
         if (d.has_aero) {
             const FT *mass = as.aero_mass + (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
-            unsigned char any = 0;
+            int any = 0;
             for (int ia = 0; ia < RRTMGP_N_AEROSOLS; ia++) any |= (mass[ia] > FT(0));  // aerosol_optics.jl:464-483
-            sh.aero_mask[k] = any;
-            loc_factor_gen(ld[4 * k + 3], aero->rh_levels, aero->nrh, sh.rh_loc[k], sh.rh_f[k]);
+            rec.aero_mask = any;
+            loc_factor_gen(ld[4 * k + 3], aero->rh_levels, aero->nrh, rec.rh_loc, rec.rh_f);
         }
+        sh.lay[k] = rec;
     }
     // gas table: row ig (1-based gas index), row 0 = 1
     for (int i = tid; i < d.ngas1 * nlay; i += nt) {
@@ -354,20 +352,21 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         sh.vmr[i] = v;
     }
     if (d.lw)
-        for (int k = tid; k < nlev; k += nt)
-            planck_pos(as.t_lev[(size_t)nlev * col + k], lk.t_planck, lk.n_t_plnk, sh.pl_lev_loc[k], sh.pl_lev_f[k]);
+        for (int k = tid; k < nlev; k += nt) {
+            LevelRec<FT> lr;
+            planck_pos(as.t_lev[(size_t)nlev * col + k], lk.t_planck, lk.n_t_plnk, lr.loc, lr.f);
+            sh.lev[k] = lr;
+        }
     if (tid == 0) {
         if (d.lw) planck_pos(as.t_sfc[col], lk.t_planck, lk.n_t_plnk, sh.misc[d.nwaves], sh.miscf[0]);
         for (int w = 0; w < d.nwaves; w++) sh.misc[w] = 0;
     }
     __syncthreads();
-    for (int k = tid; k < nlay; k += nt)
-        sh.dry_fact[k] = FT(1) / (FT(1) + sh.lay[k].w);  // gas_optics.jl:367
     if (d.has_cld && tid == 0) {
         // _get_start / _get_finish, cloud_optics.jl:310-322 (0-based, -1 when clear)
         int start = -1, finish = -1;
-        for (int k = 0; k < nlay; k++) if (sh.cld_frac[k] > FT(0)) { start = k; break; }
-        for (int k = nlay - 1; k >= 0; k--) if (sh.cld_frac[k] > FT(0)) { finish = k; break; }
+        for (int k = 0; k < nlay; k++) if (sh.lay[k].cld_frac > FT(0)) { start = k; break; }
+        for (int k = nlay - 1; k >= 0; k--) if (sh.lay[k].cld_frac > FT(0)) { finish = k; break; }
         sh.misc[d.nwaves + 1] = start;
         sh.misc[d.nwaves + 2] = finish;
     }
@@ -399,12 +398,13 @@ template <typename FT>
 __device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShared<FT> &sh, int ibnd, int ice_rgh, int k,
                                             FT &tl, FT &tls, FT &tlsg, FT &ti, FT &tis, FT &tisg) {
     tl = tls = tlsg = ti = tis = tisg = FT(0);
-    const FT pl = sh.path_liq[k], pi = sh.path_ice[k];
+    const LayerRec<FT> &L = sh.lay[k];
+    const FT pl = L.path_liq, pi = L.path_ice;
     if (pl > Num<FT>::eps()) {
         const int nl = lc.nsize_liq;
         const FT *t = lc.liqdata + (size_t)(3 * nl) * ibnd;
-        const int loc = sh.liq_loc[k];
-        const FT fac = sh.liq_fac[k], fc1 = FT(1) - fac;
+        const int loc = L.liq_loc;
+        const FT fac = L.liq_fac, fc1 = FT(1) - fac;
         tl = m_max((fc1 * t[loc] + fac * t[loc + 1]) * pl, FT(0));
         tls = (fc1 * t[nl + loc] + fac * t[nl + loc + 1]) * tl;
         tlsg = (fc1 * t[2 * nl + loc] + fac * t[2 * nl + loc + 1]) * tls;
@@ -412,8 +412,8 @@ __device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShare
     if (pi > Num<FT>::eps()) {
         const int ni = lc.nsize_ice;
         const FT *t = lc.icedata + (size_t)(3 * ni) * ((size_t)ibnd + (size_t)lc.nband * (ice_rgh - 1));
-        const int loc = sh.ice_loc[k];
-        const FT fac = sh.ice_fac[k], fc1 = FT(1) - fac;
+        const int loc = L.ice_loc;
+        const FT fac = L.ice_fac, fc1 = FT(1) - fac;
         ti = m_max((fc1 * t[loc] + fac * t[loc + 1]) * pi, FT(0));
         tis = (fc1 * t[ni + loc] + fac * t[ni + loc + 1]) * ti;
         tisg = (fc1 * t[2 * ni + loc] + fac * t[2 * ni + loc + 1]) * tis;
@@ -425,8 +425,8 @@ template <typename FT>
 __device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT> &sh, const FT *mass, const FT *size,
                                       int ibnd, int k, FT &tc, FT &tsc, FT &tsgc) {
     const int nrh = la.nrh, nbin = la.nbin;
-    const int loc = sh.rh_loc[k];
-    const FT f = sh.rh_f[k], omf = FT(1) - f;
+    const int loc = sh.lay[k].rh_loc;
+    const FT f = sh.lay[k].rh_f, omf = FT(1) - f;
     FT t_cum = FT(0), ts_cum = FT(0), tsg_cum = FT(0);
     auto size_bin = [&](FT sz) {  // locate_merra_size_bin, aerosol_optics.jl:438-451
         int bin = 0;
@@ -490,8 +490,8 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
     for (int u = tid; u < CH * nb; u += nt) {
         const int b = u / CH, kk = u % CH, k = k0 + kk;  // CH is a power of two
         if (kk >= kn) continue;
-        const int t = kk * nb + b;
-        const int li = sh.lay_idx[k];
+        const int t = kk * NBMAX + b;
+        const int li = sh.lay[k].idx;
         const int jT = li & 0xff, tropo = li >> 16;
         const int ig0 = lk.key_species[0 + 2 * (tropo + 2 * b)], ig1 = lk.key_species[1 + 2 * (tropo + 2 * b)];
         const FT vmr1 = sh.vmr[ig0 * nlay + k], vmr2 = sh.vmr[ig1 * nlay + k];
@@ -512,13 +512,15 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
             fe[it] = loc_eta - FT(j);
             cm[it] = col_mix;
         }
-        sh.c_je[t] = je[0] | (je[1] << 8);
-        sh.c_eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
-        if (d.lw) sh.c_Blay[t] = lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k]] * (FT(1) - sh.pl_lay_f[k]) +
-                                 lk.tot_planck[(size_t)lk.n_t_plnk * b + sh.pl_lay_loc[k] + 1] * sh.pl_lay_f[k];
+        sh.ch->je[t] = je[0] | (je[1] << 8);
+        sh.ch->eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
+        if (d.lw) {
+            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lay[k].pl_lay_loc;
+            sh.ch->Blay[t] = tp[0] * (FT(1) - sh.lay[k].pl_lay_f) + tp[1] * sh.lay[k].pl_lay_f;
+        }
         if (d.has_cld) {
             FT c0 = FT(0), c1 = FT(0), c2 = FT(0);
-            if (sh.cld_frac[k] > FT(0)) {
+            if (sh.lay[k].cld_frac > FT(0)) {
                 FT tl, tls, tlsg, ti, tis, tisg;
                 cloud_props(*cld, sh, b, as.ice_rgh, k, tl, tls, tlsg, ti, tis, tisg);
                 if (d.twostream) {  // add_cloud_optics_2stream!, cloud_optics.jl:120-130
@@ -532,15 +534,15 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     c0 = (tl - tls) + (ti - tis);  // cloud_optics.jl:45
                 }
             }
-            sh.c_cld[t] = V4<FT>{c0, c1, c2, FT(0)};
+            sh.ch->cld[t] = V4<FT>{c0, c1, c2, FT(0)};
         }
         if (d.has_aero) {
             FT a0 = FT(0), a1 = FT(0), a2 = FT(0);
-            if (sh.aero_mask[k]) {
+            if (sh.lay[k].aero_mask) {
                 const size_t o = (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
                 FT ta, tsa, tsga;
                 lookup_aerosol(*aero, sh, as.aero_mass + o, as.aero_size + o, b, k, ta, tsa, tsga);
-                if (!d.lw && b == aero->iband_550nm - 1) { sh.aod_lay[k] = ta; sh.aod_lay[nlay + k] = tsa; }
+                if (!d.lw && b == aero->iband_550nm - 1) { sh.lay[k].aod_t = ta; sh.lay[k].aod_ts = tsa; }
                 if (d.twostream) {  // aerosol_optics.jl:113-122
                     FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);
                     FT ssa_aero = tsa / m_max(Num<FT>::eps(), ta);
@@ -550,38 +552,38 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     a0 = ta - tsa;  // aerosol_optics.jl:45
                 }
             }
-            sh.c_aer[t] = V4<FT>{a0, a1, a2, FT(0)};
+            sh.ch->aer[t] = V4<FT>{a0, a1, a2, FT(0)};
         }
     }
     // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0)
     for (int t = tid; t < d.max_int * CH; t += nt) {
         const int i = t / CH, kk = t % CH, k = k0 + kk;
         if (kk >= kn) continue;
-        const int tropo = sh.lay_idx[k] >> 16;
+        const int tropo = sh.lay[k].idx >> 16;
         FT scaling = FT(0);
         if (i < (tropo ? lk.m_nint[1] : lk.m_nint[0])) {
             const int *gd = (tropo ? lk.m_gasdata[1] : lk.m_gasdata[0]) + 4 * i;
             const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
             if (vmr_imnr > FT(0)) {
-                scaling = vmr_imnr * sh.lay[k].z;
+                scaling = vmr_imnr * sh.lay[k].col_dry;
                 if (gd[2] == 1) {
-                    scaling *= sh.dens_fact[k];
+                    scaling *= sh.lay[k].dens_fact;
                     if (gd[1] > 0) {
                         const FT vs = sh.vmr[gd[1] * nlay + k];
-                        if (gd[3] == 1) scaling *= (FT(1) - vs * sh.dry_fact[k]);
-                        else scaling *= vs * sh.dry_fact[k];
+                        if (gd[3] == 1) scaling *= (FT(1) - vs * sh.lay[k].dry_fact);
+                        else scaling *= vs * sh.lay[k].dry_fact;
                     }
                 }
             }
         }
-        sh.c_mscale[i * CH + kk] = scaling;
+        sh.mscale[i * CH + kk] = scaling;
     }
     if (d.lw)  // Planck band sources at levels k0 .. k0 + kn  (interp1d_equispaced, compute_optical_props.jl:180-186)
         for (int u = tid; u < 2 * CH * nb; u += nt) {
             const int b = u / (2 * CH), kk = u % (2 * CH), lev = k0 + kk;
             if (kk > kn) continue;
-            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.pl_lev_loc[lev];
-            sh.c_Blev[kk * nb + b] = tp[0] * (FT(1) - sh.pl_lev_f[lev]) + tp[1] * sh.pl_lev_f[lev];
+            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lev[lev].loc;
+            sh.ch->Blev[kk * NBMAX + b] = tp[0] * (FT(1) - sh.lev[lev].f) + tp[1] * sh.lev[lev].f;
         }
 }
 
@@ -627,14 +629,14 @@ template <typename FT, bool SW>
 __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
                                            int nb, FT &tau, FT &ssa, FT &pfrac) {
     constexpr unsigned E = sizeof(FT), EK = SW ? E : 2 * E;  // LW: (kmajor, planck_fraction) pairs
-    const int li = sh.lay_idx[k];
+    const LayerRec<FT> &L = sh.lay[k];
+    const int li = L.idx;
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
-    const V4<FT> lr = sh.lay[k];
-    const FT fT = lr.x, fP = lr.y, col_dry = lr.z;
-    const int r = kk * nb + lb.ibnd;
-    const unsigned jep = sh.c_je[r];
+    const FT fT = L.fT, fP = L.fP, col_dry = L.col_dry;
+    const int r = kk * NBMAX + lb.ibnd;
+    const unsigned jep = sh.ch->je[r];
     const unsigned je1 = jep & 0xff, je2 = jep >> 8;
-    const V4<FT> er = sh.c_eta[r];
+    const V4<FT> er = sh.ch->eta[r];
     const FT fe1 = er.x, fe2 = er.y, cm1 = er.z, cm2 = er.w;
     const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe1, omfe2 = FT(1) - fe2;
     const unsigned NE = lk.n_eta, NG = lk.n_gpt;
@@ -669,7 +671,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
         const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.m_koff(tropo) * E;
         const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.m_koff(tropo) * E;
-        const FT *ms = sh.c_mscale + lb.m_st(tropo) * CH + kk;
+        const FT *ms = sh.mscale + lb.m_st(tropo) * CH + kk;
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
         // groups of MG intervals: every load of a group is in flight before the first use; slots past
         // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
@@ -702,7 +704,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         const unsigned r1 = __umul24(jT * NE + je1, sR) + lb.g * E, r2 = __umul24((jT + 1) * NE + je2, sR) + lb.g * E;
         const FT kr = omfe1 * omfT * ldg<FT>(rc, r1) + fe1 * omfT * ldg<FT>(rc, r1 + sR) + omfe2 * fT * ldg<FT>(rc, r2) +
                       fe2 * fT * ldg<FT>(rc, r2 + sR);
-        const FT tau_ray = kr * (lr.w + FT(1)) * col_dry;
+        const FT tau_ray = kr * (L.h2o + FT(1)) * col_dry;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
         ssa = tau_ray * m_rcp(tau);
         if (tau <= FT(0)) ssa = FT(0);
@@ -719,13 +721,13 @@ __device__ inline bool build_cloud_mask(const ColShared<FT> &sh, const ColDims &
     const int start = sh.misc[d.nwaves + 1], finish = sh.misc[d.nwaves + 2];
     if (start < 0) return false;
     int draw = 0;
-    FT cf_above = sh.cld_frac[finish];
+    FT cf_above = sh.lay[finish].cld_frac;
     double r_above = mcica_draw(key, draw++);
     bool mask_above = r_above >= (double)(FT(1) - cf_above);
     auto setbit = [&](int k) { if (k < 64) m0 |= (1ULL << k); else m1 |= (1ULL << (k - 64)); };
     if (mask_above) setbit(finish);
     for (int k = finish - 1; k >= start; k--) {
-        const FT cf = sh.cld_frac[k];
+        const FT cf = sh.lay[k].cld_frac;
         bool mk;
         if (cf > FT(0)) {
             const double r = mask_above ? r_above : mcica_draw(key, draw++) * (double)(FT(1) - cf_above);

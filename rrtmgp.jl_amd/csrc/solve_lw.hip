@@ -69,14 +69,14 @@ __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColSh
     const int nb = a.dims.nbnd;
     gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
     g = FT(0);
-    const int r = kk * nb + lb.ibnd;
+    const int r = kk * NBMAX + lb.ibnd;
     if (a.dims.has_cld && mask_bit(m0, m1, k)) {
-        const V4<FT> c = sh.c_cld[r];
+        const V4<FT> c = sh.ch->cld[r];
         if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
         else tau += c.x;
     }
-    if (a.dims.has_aero && sh.aero_mask[k]) {
-        const V4<FT> c = sh.c_aer[r];
+    if (a.dims.has_aero && sh.lay[k].aero_mask) {
+        const V4<FT> c = sh.ch->aer[r];
         if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
         else tau += c.x;
     }
@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
                     lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
-                    const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
-                    const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
+                    const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
+                    const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
                     FT lev_src_k;
                     if (k == 0) {
                         const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
@@ -199,9 +199,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
                     lw_layer_optics<FT, false>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
-                    const FT lev_src_dec = sh.c_Blev[kk * nb + lb.ibnd] * pfrac;
-                    const FT lev_src_inc = sh.c_Blev[(kk + 1) * nb + lb.ibnd] * pfrac;
-                    const FT lay_src = sh.c_Blay[kk * nb + lb.ibnd] * pfrac;
+                    const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
+                    const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
+                    const FT lay_src = sh.ch->Blay[kk * NBMAX + lb.ibnd] * pfrac;
                     FT lev_src;
                     if (k == 0) {
                         const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
@@ -295,6 +295,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const int threads = ((lk.n_gpt + 63) / 64) * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
+    RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;

@@ -164,11 +164,11 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                 prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
-                    const int k = k0 + kk, r = kk * nb + lb.ibnd;
+                    const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
                     FT tau, ssa, pf, gg = FT(0);
                     gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
-                    if (d.has_cld && mask_bit(m0, m1, k)) { const V4<FT> cr = sh.c_cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
-                    if (d.has_aero && sh.aero_mask[k]) { const V4<FT> cr = sh.c_aer[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
+                    if (d.has_cld && mask_bit(m0, m1, k)) { const V4<FT> cr = sh.ch->cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
+                    if (d.has_aero && sh.lay[k].aero_mask) { const V4<FT> cr = sh.ch->aer[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
                     tau_cum += tau;
                     const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
                     FT Rdir, Tdir, Rdif, Tdif;
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             // the 550 nm AOD: sum over masked layers in layer order (aerosol_optics.jl:96-116)
             FT e = FT(0), s = FT(0);
             for (int k = 0; k < nlay; k++)
-                if (sh.aero_mask[k]) { e += sh.aod_lay[k]; s += sh.aod_lay[nlay + k]; }
+                if (sh.lay[k].aero_mask) { e += sh.lay[k].aod_t; s += sh.lay[k].aod_ts; }
             a.as.aod_sw_ext[col] = e;
             a.as.aod_sw_sca[col] = s;
         }
@@ -258,6 +258,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
+    RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
     d.nwaves = threads / 64; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
