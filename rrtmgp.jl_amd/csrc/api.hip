@@ -93,43 +93,52 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
     g.is_sw = d->is_sw; g.n_gpt = (int)NG; g.n_bnd = (int)NB; g.n_eta = (int)NE; g.n_pp = (int)NP; g.n_t_ref = (int)NT;
     g.n_gases = (int)d->n_gases; g.n_t_plnk = (int)d->n_t_plnk; g.idx_h2o = (int)d->idx_h2o;
     g.p_ref_tropo = (FT)d->p_ref_tropo;
+    // host image of the gather arena; pieces start on 256-byte boundaries
+    std::vector<FT> arena;
+    auto arena_piece = [&](size_t n) -> size_t {
+        const size_t at = (arena.size() + 63) & ~size_t(63);
+        arena.resize(at + n, FT(0));
+        return at;
+    };
     // (n_eta, n_p, n_t, n_gpt) -> [t][p][eta][gpt]
-    auto relayout4 = [&](const void *src, const FT **out) -> int {
+    auto relayout4 = [&](const void *src, unsigned *off) -> int {
         const FT *s = (const FT *)src;
-        std::vector<FT> h((size_t)NE * NP * NT * NG);
+        const size_t at = arena_piece((size_t)NE * NP * NT * NG);
         for (int64_t gq = 0; gq < NG; gq++)
             for (int64_t t = 0; t < NT; t++)
                 for (int64_t p = 0; p < NP; p++)
                     for (int64_t e = 0; e < NE; e++)
-                        h[((t * NP + p) * NE + e) * NG + gq] = s[e + NE * (p + NP * (t + NT * gq))];
-        return upload(lk, h, out);
+                        arena[at + ((t * NP + p) * NE + e) * NG + gq] = s[e + NE * (p + NP * (t + NT * gq))];
+        *off = (unsigned)(at * sizeof(FT));
+        return RRTMGP_OK;
     };
     // (n_eta, n_t, n) -> [t][eta][perm(n)]
-    auto relayout3 = [&](const void *src, int64_t n, const std::vector<int64_t> &dst_of_src, const FT **out) -> int {
+    auto relayout3 = [&](const void *src, int64_t n, const std::vector<int64_t> &dst_of_src, unsigned *off) -> int {
         const FT *s = (const FT *)src;
-        std::vector<FT> h((size_t)NE * NT * std::max<int64_t>(n, 1));
+        const size_t at = arena_piece((size_t)NE * NT * std::max<int64_t>(n, 1));
         for (int64_t c = 0; c < n; c++)
             for (int64_t t = 0; t < NT; t++)
-                for (int64_t e = 0; e < NE; e++) h[(t * NE + e) * n + dst_of_src[c]] = s[e + NE * (t + NT * c)];
-        return upload(lk, h, out);
+                for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * n + dst_of_src[c]] = s[e + NE * (t + NT * c)];
+        *off = (unsigned)(at * sizeof(FT));
+        return RRTMGP_OK;
     };
     g.t_planck = nullptr; g.tot_planck = nullptr;
     if (d->is_sw) {
-        TRY(relayout4(d->kmajor, &g.kmajor));
+        TRY(relayout4(d->kmajor, &g.off_kmajor));
     } else {
         RR_CHECK(d->planck_fraction && d->t_planck && d->tot_planck && d->n_t_plnk >= 2, "LW lookup: missing Planck tables");
         // (kmajor, planck_fraction) interleaved: one 8-byte (Float32) load per interpolation corner
         const FT *sk = (const FT *)d->kmajor, *sp = (const FT *)d->planck_fraction;
-        std::vector<FT> h((size_t)2 * NE * NP * NT * NG);
+        const size_t at = arena_piece((size_t)2 * NE * NP * NT * NG);
         for (int64_t gq = 0; gq < NG; gq++)
             for (int64_t t = 0; t < NT; t++)
                 for (int64_t p = 0; p < NP; p++)
                     for (int64_t e = 0; e < NE; e++) {
-                        const size_t src = e + NE * (p + NP * (t + NT * gq)), dst = 2 * (((t * NP + p) * NE + e) * NG + gq);
-                        h[dst] = sk[src];
-                        h[dst + 1] = sp[src];
+                        const size_t src = e + NE * (p + NP * (t + NT * gq)), dst = at + 2 * (((t * NP + p) * NE + e) * NG + gq);
+                        arena[dst] = sk[src];
+                        arena[dst + 1] = sp[src];
                     }
-        TRY(upload(lk, h, &g.kmajor));
+        g.off_kmajor = (unsigned)(at * sizeof(FT));
         TRY(upload_raw<FT>(lk, d->t_planck, d->n_t_plnk, &g.t_planck));
         TRY(upload_raw<FT>(lk, d->tot_planck, d->n_t_plnk * NB, &g.tot_planck));
     }
@@ -192,21 +201,26 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         TRY(upload(lk, koff, &g.m_koff[r]));
         if (m->n_contrib > 0) {
             RR_CHECK(m->kminor, "minor lookup: missing kminor");
-            TRY(relayout3(m->kminor, m->n_contrib, dst, &g.m_kminor[r]));
+            TRY(relayout3(m->kminor, m->n_contrib, dst, &g.off_kminor[r]));
         } else {
-            std::vector<FT> z((size_t)NE * NT, FT(0));
-            TRY(upload(lk, z, &g.m_kminor[r]));
+            g.off_kminor[r] = (unsigned)(arena_piece((size_t)NE * NT) * sizeof(FT));
         }
     }
-    g.rayl[0] = g.rayl[1] = nullptr;
+    g.off_rayl[0] = g.off_rayl[1] = 0;
     g.solar_src_scaled = nullptr;
     if (d->is_sw) {
         RR_CHECK(d->rayl_lower && d->rayl_upper && d->solar_src_scaled, "SW lookup: missing Rayleigh / solar tables");
         std::vector<int64_t> ident(NG);
         for (int64_t i = 0; i < NG; i++) ident[i] = i;
-        TRY(relayout3(d->rayl_lower, NG, ident, &g.rayl[0]));
-        TRY(relayout3(d->rayl_upper, NG, ident, &g.rayl[1]));
+        TRY(relayout3(d->rayl_lower, NG, ident, &g.off_rayl[0]));
+        TRY(relayout3(d->rayl_upper, NG, ident, &g.off_rayl[1]));
         TRY(upload_raw<FT>(lk, d->solar_src_scaled, NG, &g.solar_src_scaled));
+    }
+    RR_CHECK((double)arena.size() * sizeof(FT) < 4.0e9, "gas lookup too large for 32-bit table offsets");
+    {
+        const FT *dev = nullptr;
+        TRY(upload(lk, arena, &dev));
+        g.arena = (const char *)dev;
     }
     return RRTMGP_OK;
 }

@@ -22,7 +22,12 @@ template <typename FT>
 struct DevGas {
     int is_sw, n_gpt, n_bnd, n_eta, n_pp /* n_p_ref + 1 */, n_t_ref, n_gases, n_t_plnk, idx_h2o;
     FT p_ref_tropo;
-    const FT *kmajor;      // SW: [t][p][eta][gpt]; LW: [t][p][eta][gpt][2] = (kmajor, planck_fraction) pairs
+    // the tables the g-point lanes gather from live in ONE allocation (one scalar base address for
+    // every global_load of the hot loop); offsets in bytes:
+    const char *arena;
+    unsigned off_kmajor;     // SW: [t][p][eta][gpt]; LW: [t][p][eta][gpt][2] = (kmajor, planck_fraction) pairs
+    unsigned off_kminor[2];  // [t][eta][contrib], contrib = koff[b] + i*ng_b + (g - lo_b); region 0 lower, 1 upper
+    unsigned off_rayl[2];    // [t][eta][gpt]   (SW)
     const FT *t_planck;    // [n_t_plnk]                  (LW)
     const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
     const FT *ln_p_ref;    // [n_p_ref]
@@ -36,10 +41,8 @@ struct DevGas {
     const int *m_bnd_st[2];   // [n_bnd+1] 0-based start into gasdata columns
     const int *m_gasdata[2];  // (4, n_min_absrb)
     const int *m_koff[2];     // [n_bnd] offset of the band's block along the contributor axis
-    const FT *m_kminor[2];    // [t][eta][contrib], contrib = koff[b] + i*ng_b + (g - lo_b)
     int m_ncontrib[2];
     int m_nint[2];            // minor intervals (gasdata columns) per region
-    const FT *rayl[2];           // [t][eta][gpt]   (SW)
     const FT *solar_src_scaled;  // [n_gpt]         (SW)
 };
 

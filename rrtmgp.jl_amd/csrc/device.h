@@ -591,11 +591,13 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
 // (explicit lower/upper members: arrays indexed by the run-time region would live in scratch memory)
 struct LaneBand {
     int g, ibnd, ngb;
-    int m_pack;  // st0 | n0 << 8 | st1 << 16 | n1 << 24   (minor-interval start / count per region)
-    int m_koff0, m_koff1;
+    int m_pack;          // st0 | n0 << 8 | st1 << 16 | n1 << 24   (minor-interval start / count per region)
+    unsigned gk;         // arena byte offset of this lane's g-point in the kmajor table
+    unsigned gm0, gm1;   // ... of this lane's first contributor in kminor lower / upper
+    unsigned gE;         // g * sizeof(FT)
     __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }
     __device__ __forceinline__ int m_n(unsigned tropo) const { return (m_pack >> (tropo ? 24 : 8)) & 0xff; }
-    __device__ __forceinline__ int m_koff(unsigned tropo) const { return tropo ? m_koff1 : m_koff0; }
+    __device__ __forceinline__ unsigned gm(unsigned tropo) const { return tropo ? gm1 : gm0; }
 };
 
 template <typename FT>
@@ -608,8 +610,11 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     const int st0 = lk.m_bnd_st[0][lb.ibnd], st1 = lk.m_bnd_st[1][lb.ibnd];
     const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - st0, n1 = lk.m_bnd_st[1][lb.ibnd + 1] - st1;
     lb.m_pack = st0 | (n0 << 8) | (st1 << 16) | (n1 << 24);
-    lb.m_koff0 = lk.m_koff[0][lb.ibnd] + gi;
-    lb.m_koff1 = lk.m_koff[1][lb.ibnd] + gi;
+    constexpr unsigned E = sizeof(FT);
+    lb.gE = g * E;
+    lb.gk = lk.off_kmajor + g * (lk.is_sw ? E : 2 * E);
+    lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi) * E;
+    lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi) * E;
     return lb;
 }
 
@@ -643,20 +648,20 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
     const unsigned sE = NG * EK, sP = NE * sE;
     const unsigned row = (jT * lk.n_pp + jP) * NE;  // (t, p) row, in eta units
-    const unsigned o1 = __umul24(row + je1, sE) + lb.g * EK;
-    const unsigned o2 = __umul24(row + lk.n_pp * NE + je2, sE) + lb.g * EK;
+    const unsigned o1 = __umul24(row + je1, sE) + lb.gk;
+    const unsigned o2 = __umul24(row + lk.n_pp * NE + je2, sE) + lb.gk;
     FT k000, k100, k010, k110, q000, q100, q010, q110;
     FT p000 = 0, p100 = 0, p010 = 0, p110 = 0, r000 = 0, r100 = 0, r010 = 0, r110 = 0;
     if (SW) {
-        k000 = ldg<FT>(lk.kmajor, o1); k100 = ldg<FT>(lk.kmajor, o1 + sE);
-        k010 = ldg<FT>(lk.kmajor, o1 + sP); k110 = ldg<FT>(lk.kmajor, o1 + sP + sE);
-        q000 = ldg<FT>(lk.kmajor, o2); q100 = ldg<FT>(lk.kmajor, o2 + sE);
-        q010 = ldg<FT>(lk.kmajor, o2 + sP); q110 = ldg<FT>(lk.kmajor, o2 + sP + sE);
+        k000 = ldg<FT>(lk.arena, o1); k100 = ldg<FT>(lk.arena, o1 + sE);
+        k010 = ldg<FT>(lk.arena, o1 + sP); k110 = ldg<FT>(lk.arena, o1 + sP + sE);
+        q000 = ldg<FT>(lk.arena, o2); q100 = ldg<FT>(lk.arena, o2 + sE);
+        q010 = ldg<FT>(lk.arena, o2 + sP); q110 = ldg<FT>(lk.arena, o2 + sP + sE);
     } else {
-        const V2<FT> a = ldg<V2<FT>>(lk.kmajor, o1), b = ldg<V2<FT>>(lk.kmajor, o1 + sE);
-        const V2<FT> c = ldg<V2<FT>>(lk.kmajor, o1 + sP), d = ldg<V2<FT>>(lk.kmajor, o1 + sP + sE);
-        const V2<FT> e = ldg<V2<FT>>(lk.kmajor, o2), f = ldg<V2<FT>>(lk.kmajor, o2 + sE);
-        const V2<FT> g = ldg<V2<FT>>(lk.kmajor, o2 + sP), h = ldg<V2<FT>>(lk.kmajor, o2 + sP + sE);
+        const V2<FT> a = ldg<V2<FT>>(lk.arena, o1), b = ldg<V2<FT>>(lk.arena, o1 + sE);
+        const V2<FT> c = ldg<V2<FT>>(lk.arena, o1 + sP), d = ldg<V2<FT>>(lk.arena, o1 + sP + sE);
+        const V2<FT> e = ldg<V2<FT>>(lk.arena, o2), f = ldg<V2<FT>>(lk.arena, o2 + sE);
+        const V2<FT> g = ldg<V2<FT>>(lk.arena, o2 + sP), h = ldg<V2<FT>>(lk.arena, o2 + sP + sE);
         k000 = a.x; k100 = b.x; k010 = c.x; k110 = d.x; q000 = e.x; q100 = f.x; q010 = g.x; q110 = h.x;
         p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
     }
@@ -667,10 +672,10 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     FT tau_minor = FT(0);
     const int n = lb.m_n(tropo);
     if (n > 0) {
-        const FT *kmn = tropo ? lk.m_kminor[1] : lk.m_kminor[0];
+        const char *kmn = lk.arena;
         const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
-        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.m_koff(tropo) * E;
-        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.m_koff(tropo) * E;
+        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
+        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
         const FT *ms = sh.mscale + lb.m_st(tropo) * CH + kk;
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
         // groups of MG intervals: every load of a group is in flight before the first use; slots past
@@ -683,8 +688,9 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
             for (int j = 0; j < MG; j++) {
                 const int i = (i0 + j < n) ? i0 + j : n - 1;
                 const unsigned c = __umul24((unsigned)i, cstep);
-                c11[j] = ldg<FT>(kmn, a1 + c); c21[j] = ldg<FT>(kmn, a1 + NCb + c);
-                c12[j] = ldg<FT>(kmn, a2 + c); c22[j] = ldg<FT>(kmn, a2 + NCb + c);
+                const unsigned x1 = a1 + c, x2 = a2 + c;
+                c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn, x1 + NCb);
+                c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn, x2 + NCb);
                 sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
             }
 #pragma unroll
@@ -699,9 +705,9 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         ssa = FT(0);
     } else {
         // compute_tau_rayleigh, gas_optics.jl:430-444
-        const FT *rc = tropo ? lk.rayl[1] : lk.rayl[0];
-        const unsigned sR = NG * E;
-        const unsigned r1 = __umul24(jT * NE + je1, sR) + lb.g * E, r2 = __umul24((jT + 1) * NE + je2, sR) + lb.g * E;
+        const char *rc = lk.arena;
+        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
+        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
         const FT kr = omfe1 * omfT * ldg<FT>(rc, r1) + fe1 * omfT * ldg<FT>(rc, r1 + sR) + omfe2 * fT * ldg<FT>(rc, r2) +
                       fe2 * fT * ldg<FT>(rc, r2 + sR);
         const FT tau_ray = kr * (L.h2o + FT(1)) * col_dry;
