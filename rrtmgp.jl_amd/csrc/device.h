@@ -755,9 +755,12 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
 // ---- sweep scratch: 3 values per (level, lane), lane-contiguous ----------------------------
 template <typename FT>
 struct Sweep {
-    FT *base;  // this workgroup's slab, already offset by the lane
-    int nt;    // lanes in the workgroup
-    __device__ __forceinline__ FT &at(int lev, int a) const { return base[(unsigned)((lev * 3 + a) * nt)]; }
+    char *base;     // this workgroup's slab (wave-uniform)
+    unsigned lane;  // threadIdx.x * sizeof(FT)
+    unsigned row;   // blockDim.x * sizeof(FT)
+    __device__ __forceinline__ FT &at(int lev, int a) const {
+        return *reinterpret_cast<FT *>(base + ((unsigned)(lev * 3 + a) * row + lane));
+    }
 };
 
 // ---- write one column's broadband fluxes ---------------------------------------------------

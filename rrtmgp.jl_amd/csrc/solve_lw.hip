@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x + tid, (int)blockDim.x};
+    Sweep<FT> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x), (unsigned)(tid * sizeof(FT)),
+                 (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CH - 1) / CH;
 
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                         src = Num<FT>::pi() * emis * sfc_source;
                         lev_src_k = lev_src_dec;
                     } else {
-                        lev_src_k = m_sqrt(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
+                        lev_src_k = m_sqrt_pos(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
                         add_layer(k - 1, lev_src_k);
                     }
                     lev_src_bot = lev_src_k;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                         sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
                         lev_src = lev_src_dec;
                     } else {
-                        lev_src = m_sqrt(inc_prev * lev_src_dec);
+                        lev_src = m_sqrt_pos(inc_prev * lev_src_dec);
                     }
                     sw.at(k, 0) = tau;
                     sw.at(k, 1) = lay_src;

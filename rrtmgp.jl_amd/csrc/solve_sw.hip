@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x + tid, (int)blockDim.x};
+    Sweep<FT> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x), (unsigned)(tid * sizeof(FT)),
+                 (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CH - 1) / CH;
