@@ -95,6 +95,7 @@ struct SwBcsDesc
 end
 struct FluxOutDesc
     mem::Int32; layout::Int32; flux_up::P; flux_dn::P; flux_net::P; flux_dn_dir::P
+    band_flux_up::P; band_flux_dn::P; band_flux_net::P
 end
 struct SolveOpts
     n_gauss_angles::Int32; metric_mem::Int32; metric_scaling::P; seed::UInt64; col_offset::Int64
@@ -215,8 +216,14 @@ function state_desc(as::AtmosphericState, use_cld::Bool, use_aero::Bool)
 end
 
 # FluxLW / FluxSW on a non-CPU device hold plain (ncol, nlev) arrays (Fluxes.jl:45-49)
-flux_desc(f::FluxLW) = FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), C_NULL)
-flux_desc(f::FluxSW) = FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), ptr(f.flux_dn_dir))
+# FluxBand keeps (nlev, ncol, n_bnd) (Fluxes.jl:170-186); its flux_net is filled later by
+# update_net_fluxes! (update_fluxes.jl:198-201), so the solve is not asked for it.
+band_ptrs(::Nothing) = (C_NULL, C_NULL, C_NULL)
+band_ptrs(b) = (ptr(b.flux_up), ptr(b.flux_dn), C_NULL)
+flux_desc(f::FluxLW, band = nothing) =
+    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), C_NULL, band_ptrs(band)...)
+flux_desc(f::FluxSW, band = nothing) =
+    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), ptr(f.flux_dn_dir), band_ptrs(band)...)
 
 # McICA: the host seeds Random (update_fluxes.jl:149-156); one draw from it keys the counter-based stream
 opts(n_angles = 1) = SolveOpts(Int32(n_angles), 0, C_NULL, rand(UInt64), 0)
@@ -225,16 +232,15 @@ opts(n_angles = 1) = SolveOpts(Int32(n_angles), 0, C_NULL, rand(UInt64), 0)
 function rte_lw_2stream_solve!(dev::HIPDevice, flux::FluxLW, flux_lw::FluxLW, band_flux, src_lw::SourceLW2Str,
                                bcs_lw::LwBCs, op::TwoStream, as::AtmosphericState, state_cache, lookup_lw::LookUpLW,
                                lookup_lw_cld = nothing, lookup_lw_aero = nothing)
-    isnothing(band_flux) || error("per-band fluxes are not implemented by the HIP back end yet")
     FT = eltype(flux_lw.flux_up)
     nlay, ncol = size(as.layerdata, 2), size(as.layerdata, 3)
     ws = workspace(dev, ncol, nlay, FT)
-    GC.@preserve as bcs_lw flux_lw lookup_lw check(ccall(
+    GC.@preserve as bcs_lw flux_lw band_flux lookup_lw check(ccall(
         (:rrtmgp_hip_rte_lw_2stream_solve, libhip[]), Cint,
         (P, P, P, P, Ref{AtmosStateDesc}, Ref{LwBcsDesc}, Ref{FluxOutDesc}, Ref{SolveOpts}),
         ws, lookup_handle(dev, lookup_lw), lookup_handle(dev, lookup_lw_cld), lookup_handle(dev, lookup_lw_aero),
         state_desc(as, !isnothing(lookup_lw_cld), !isnothing(lookup_lw_aero)),
-        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw), opts()))
+        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw, band_flux), opts()))
     return nothing
 end
 
@@ -257,17 +263,16 @@ end
 function rte_sw_2stream_solve!(dev::HIPDevice, flux::FluxSW, flux_sw::FluxSW, band_flux, op::TwoStream, bcs_sw::SwBCs,
                                src_sw::SourceSW2Str, as::AtmosphericState, state_cache, lookup_sw::LookUpSW,
                                lookup_sw_cld = nothing, lookup_sw_aero = nothing)
-    isnothing(band_flux) || error("per-band fluxes are not implemented by the HIP back end yet")
     FT = eltype(flux_sw.flux_up)
     nlay, ncol = size(as.layerdata, 2), size(as.layerdata, 3)
     ws = workspace(dev, ncol, nlay, FT)
-    GC.@preserve as bcs_sw flux_sw lookup_sw check(ccall(
+    GC.@preserve as bcs_sw flux_sw band_flux lookup_sw check(ccall(
         (:rrtmgp_hip_rte_sw_2stream_solve, libhip[]), Cint,
         (P, P, P, P, Ref{AtmosStateDesc}, Ref{SwBcsDesc}, Ref{FluxOutDesc}, Ref{SolveOpts}),
         ws, lookup_handle(dev, lookup_sw), lookup_handle(dev, lookup_sw_cld), lookup_handle(dev, lookup_sw_aero),
         state_desc(as, !isnothing(lookup_sw_cld), !isnothing(lookup_sw_aero)),
         SwBcsDesc(0, 0, ptr(bcs_sw.cos_zenith), ptr(bcs_sw.toa_flux), ptr(bcs_sw.sfc_alb_direct),
-                  ptr(bcs_sw.sfc_alb_diffuse)), flux_desc(flux_sw), opts()))
+                  ptr(bcs_sw.sfc_alb_diffuse)), flux_desc(flux_sw, band_flux), opts()))
     return nothing
 end
 
@@ -303,7 +308,7 @@ function rte_lw_2stream_solve!(dev::HIPDevice, flux_lw::FluxLW, src_lw::SourceLW
         (:rrtmgp_hip_rte_lw_2stream_solve_gray, libhip[]), Cint,
         (P, Ref{GrayStateDesc}, Ref{LwBcsDesc}, Ref{FluxOutDesc}, Ref{SolveOpts}),
         workspace(dev, ncol, nlay, FT), gray_desc(as, RP.Stefan(src_lw.param_set)),
-        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw), opts()))
+        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw, band_flux), opts()))
     return nothing
 end
 
@@ -315,7 +320,7 @@ function rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW, src_lw::SourceLWN
         (:rrtmgp_hip_rte_lw_noscat_solve_gray, libhip[]), Cint,
         (P, Ref{GrayStateDesc}, Ref{LwBcsDesc}, Ref{FluxOutDesc}, Ref{SolveOpts}),
         workspace(dev, ncol, nlay, FT), gray_desc(as, RP.Stefan(src_lw.param_set)),
-        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw), opts()))
+        LwBcsDesc(0, 0, ptr(bcs_lw.sfc_emis), ptr(bcs_lw.inc_flux)), flux_desc(flux_lw, band_flux), opts()))
     return nothing
 end
 
@@ -328,7 +333,7 @@ function rte_sw_2stream_solve!(dev::HIPDevice, flux_sw::FluxSW, op::TwoStream, b
         (P, Ref{GrayStateDesc}, Ref{SwBcsDesc}, Ref{FluxOutDesc}, Ref{SolveOpts}),
         workspace(dev, ncol, nlay, FT), gray_desc(as, 0.0),
         SwBcsDesc(0, 0, ptr(bcs_sw.cos_zenith), ptr(bcs_sw.toa_flux), ptr(bcs_sw.sfc_alb_direct),
-                  ptr(bcs_sw.sfc_alb_diffuse)), flux_desc(flux_sw), opts()))
+                  ptr(bcs_sw.sfc_alb_diffuse)), flux_desc(flux_sw, band_flux), opts()))
     return nothing
 end
 

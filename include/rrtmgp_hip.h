@@ -196,6 +196,17 @@ typedef struct rrtmgp_flux_out {
     void *flux_dn;
     void *flux_net;
     void *flux_dn_dir; /* SW only; NULL for LW */
+    /* FluxBand, src/optics/Fluxes.jl:170-215: optional per-band fluxes, FT (nlev, ncol, nbnd)
+     * whatever `layout` says (the reference keeps them vertical-first), all three NULL = off.
+     * Two-stream non-gray solvers only (src/api/getters.jl:404).  Zeroed, accumulated per
+     * g-point into the g-point's band and metric-scaled as RTESolver.jl:141,246 does;
+     * `band_flux_net` (may be NULL on its own) = scaled up - scaled dn, which the reference
+     * fills one step later in update_net_fluxes! (src/api/update_fluxes.jl:198-201).
+     * This back end requires every band to span whole 16-g-point groups (true of
+     * rrtmgp-data v1.9) and answers RRTMGP_EUNSUPPORTED otherwise. */
+    void *band_flux_up;
+    void *band_flux_dn;
+    void *band_flux_net;
 } rrtmgp_flux_out;
 
 /* Per-call options. */

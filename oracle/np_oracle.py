@@ -187,10 +187,13 @@ def lw_coeffs(tau, ssa, g, bot, top):
     return R, T, su, sd
 
 
-def solve_lw_2stream(lk, as_, bcs, lkc=None):
+def solve_lw_2stream(lk, as_, bcs, lkc=None, per_gpoint=False):
+    """`per_gpoint=True` returns (nlev, ncol, n_gpt) arrays instead of the g-point sums."""
     nlay, ncol = as_.layerdata.shape[1:]
     bnd = lk.major_gpt2bnd - 1
-    up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol))
+    shape = (nlay + 1, ncol, lk.n_gpt) if per_gpoint else (nlay + 1, ncol)
+    red = (lambda x: x) if per_gpoint else (lambda x: x.sum())
+    up = np.zeros(shape); dn = np.zeros(shape)
     for c in range(ncol):
         tau, ssa, pf = gas_optics_column(lk, as_, c)
         g = np.zeros_like(tau)
@@ -206,12 +209,12 @@ def solve_lw_2stream(lk, as_, bcs, lkc=None):
             alb.append(R + T * T * alb[k] * den)
             src.append(su + T * den * (src[k] + alb[k] * sd))
         F = bcs.inc_flux[c] if bcs.inc_flux is not None else np.zeros(tau.shape[1])
-        dn[nlay, c] = F.sum(); up[nlay, c] = (F * alb[nlay] + src[nlay]).sum()
+        dn[nlay, c] = red(F); up[nlay, c] = red(F * alb[nlay] + src[nlay])
         for k in range(nlay - 1, -1, -1):
             R, T, su, sd = lw_coeffs(tau[k], ssa[k], g[k], lev[k], lev[k + 1])
             den = 1 / (1 - R * alb[k])
             F = (T * F + R * src[k] + sd) * den
-            dn[k, c] = F.sum(); up[k, c] = (F * alb[k] + src[k]).sum()
+            dn[k, c] = red(F); up[k, c] = red(F * alb[k] + src[k])
     return up, dn
 
 

@@ -68,7 +68,7 @@ class SwBcs(C.Structure):
 
 class FluxOut(C.Structure):
     _fields_ = [("mem", i32), ("layout", i32), ("flux_up", vp), ("flux_dn", vp), ("flux_net", vp),
-                ("flux_dn_dir", vp)]
+                ("flux_dn_dir", vp), ("band_flux_up", vp), ("band_flux_dn", vp), ("band_flux_net", vp)]
 
 
 class SolveOpts(C.Structure):

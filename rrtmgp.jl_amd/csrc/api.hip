@@ -158,6 +158,9 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         if (lo[b] < 0) lo[b] = (int)i;
         ng[b]++;
     }
+    g.band16 = 1;
+    for (int64_t b = 0; b < NB; b++)
+        if (ng[b] == 0 || (lo[b] & 15) || (ng[b] & 15)) g.band16 = 0;
     TRY(upload(lk, ks, &g.key_species));
     TRY(upload(lk, g2b, &g.gpt2bnd));
     TRY(upload(lk, lo, &g.bnd_lo));
@@ -268,7 +271,7 @@ static int select_device(int device) {
 enum Slot {
     S_LAYERDATA = 0, S_TLEV, S_TSFC, S_VMR_H2O, S_VMR_O3, S_VMR, S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F,
     S_CLD_COVER, S_AERO_SIZE, S_AERO_MASS, S_AOD_EXT, S_AOD_SCA, S_BC0, S_BC1, S_BC2, S_BC3, S_FLUX_UP, S_FLUX_DN,
-    S_FLUX_NET, S_FLUX_DIR, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_NSLOTS
+    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_NSLOTS
 };
 
 struct Stager {
@@ -353,7 +356,7 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
 
 template <typename FT>
 static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_opts *opts, size_t ncol, size_t nlev,
-                      bool sw, DevFlux<FT> &d) {
+                      bool sw, DevFlux<FT> &d, size_t nbnd = 0) {
     RR_CHECK(f && f->flux_up && f->flux_dn && f->flux_net, "flux outputs: missing array");
     RR_CHECK(f->layout == RRTMGP_LAYOUT_NCOL_NLEV || f->layout == RRTMGP_LAYOUT_NLEV_NCOL, "bad flux layout");
     const size_t bytes = ncol * nlev * sizeof(FT);
@@ -363,6 +366,14 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
     d.dir = nullptr;
     if (sw) TRY(st.out(f->mem, S_FLUX_DIR, f->flux_dn_dir, bytes, (void **)&d.dir));
     d.layout = f->layout;
+    d.band_up = d.band_dn = d.band_net = nullptr;
+    if (f->band_flux_up || f->band_flux_dn || f->band_flux_net) {
+        RR_CHECK(nbnd > 0, "per-band fluxes are only available from the two-stream, non-gray solvers");
+        RR_CHECK(f->band_flux_up && f->band_flux_dn, "per-band fluxes: band_flux_up and band_flux_dn go together");
+        TRY(st.out(f->mem, S_BAND_UP, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
+        TRY(st.out(f->mem, S_BAND_DN, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
+        if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
+    }
     d.metric = nullptr;
     if (opts && opts->metric_scaling)
         TRY(st.in(opts->metric_mem, S_METRIC, opts->metric_scaling, bytes, (const void **)&d.metric));
@@ -402,7 +413,7 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(st.in(bcs->mem, S_BC0, bcs->sfc_emis, (size_t)lk.n_bnd * as->ncol * sizeof(FT), (const void **)&emis));
     TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
     DevFlux<FT> fl;
-    TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl));
+    TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl, twostream ? (size_t)lk.n_bnd : 0));
     TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, fl, n_angles, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
     return st.finish();
@@ -427,7 +438,7 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(st.in(bcs->mem, S_BC2, bcs->sfc_alb_direct, (size_t)lk.n_bnd * ncol * E, (const void **)&adir));
     TRY(st.in(bcs->mem, S_BC3, bcs->sfc_alb_diffuse, (size_t)lk.n_bnd * ncol * E, (const void **)&adif));
     DevFlux<FT> fl;
-    TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl));
+    TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl, twostream ? (size_t)lk.n_bnd : 0));
     TRY(launch_sw<FT>(ws, twostream, lk, cld, aero, ds, mu0, toa, adir, adif, fl, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
     return st.finish();

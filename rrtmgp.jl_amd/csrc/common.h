@@ -21,6 +21,7 @@ namespace rrtmgp {
 template <typename FT>
 struct DevGas {
     int is_sw, n_gpt, n_bnd, n_eta, n_pp /* n_p_ref + 1 */, n_t_ref, n_gases, n_t_plnk, idx_h2o;
+    int band16;  // every band starts on, and spans a multiple of, 16 g-points (one DPP row): per-band fluxes possible
     FT p_ref_tropo;
     // the tables the g-point lanes gather from live in ONE allocation (one scalar base address for
     // every global_load of the hot loop); offsets in bytes:
@@ -81,6 +82,7 @@ struct DevFlux {
     FT *up, *dn, *net, *dir;
     int layout;
     const FT *metric;  // (nlev, ncol) or nullptr
+    FT *band_up, *band_dn, *band_net;  // optional FluxBand (nlev, ncol, nbnd); band_net may be null on its own
 };
 
 // ---- host-side handles ------------------------------------------------------------

@@ -155,11 +155,28 @@ __device__ __forceinline__ FT wave_sum_to_lane63(FT v) {
     return v;
 }
 
+// Sum over each DPP row (16 lanes = one band of rrtmgp-data v1.9); every lane of the row gets it.
+template <typename FT>
+__device__ __forceinline__ FT row_sum(FT v) {
+    v += dpp_mov<0xB1, 0xF>(v);
+    v += dpp_mov<0x4E, 0xF>(v);
+    v += dpp_mov<0x141, 0xF>(v);
+    v += dpp_mov<0x140, 0xF>(v);
+    return v;
+}
+// The flux accumulators are kept per "segment": a whole wave (written by lane 63), or a
+// 16-lane row (written by its lane 15) when per-band fluxes are requested.
+template <bool BAND, typename FT>
+__device__ __forceinline__ FT seg_sum(FT v) {
+    return BAND ? row_sum(v) : wave_sum_to_lane63(v);
+}
+
 // ---- dimensions + LDS carve ----------------------------------------------------------
 struct ColDims {
     int nlay, nlev, ngas1 /* rows of the gas table */, nwaves, nbnd;
     int lw, twostream, has_cld, has_aero, n_acc /* accumulated flux components per level */;
     int max_int; /* largest minor-interval count of either region */
+    int nseg;    /* flux accumulator segments per block: nwaves, or 4 per wave with per-band fluxes */
 };
 
 // 4 values read with one ds_read_b128 (Float32) / two (Float64)
@@ -208,7 +225,7 @@ struct ColShared {
     LevelRec<FT> *lev;   // [nlev]
     FT *vmr;             // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
     FT *mscale;          // [max_int][CH] minor-gas scalings of the current chunk
-    FT *acc;             // [nwaves][nlev][n_acc]
+    FT *acc;             // [nseg][nlev][n_acc]
     int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
     FT *miscf;           // [0]: pl_sfc_f
 };
@@ -228,7 +245,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
     s.lev = carve<LevelRec<FT>>(p, d.nlev);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
     s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
-    s.acc = carve<FT>(p, (size_t)d.nwaves * d.nlev * d.n_acc);
+    s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
     return (size_t)(p - base);
@@ -768,12 +785,12 @@ struct Sweep {
 // then up, dn, net (and dir) are each multiplied by the (nlev, ncol) factor.
 template <typename FT>
 __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT> &sh, const ColDims &d, int col, int ncol,
-                                    bool zero) {
+                                    bool zero, const DevGas<FT> &lk) {
     const int nlev = d.nlev;
     for (int lev = threadIdx.x; lev < nlev; lev += blockDim.x) {
         FT c[3] = {FT(0), FT(0), FT(0)};
         if (!zero) {
-            for (int w = 0; w < d.nwaves; w++)
+            for (int w = 0; w < d.nseg; w++)
                 for (int a = 0; a < d.n_acc; a++) c[a] += sh.acc[((size_t)w * nlev + lev) * d.n_acc + a];
         }
         FT up = c[0], dn = c[1], dir = c[2];
@@ -786,6 +803,28 @@ __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT> &
                                                                : (size_t)lev + (size_t)nlev * col;
         fl.up[o] = up; fl.dn[o] = dn; fl.net[o] = net;
         if (d.n_acc == 3 && fl.dir) fl.dir[o] = dir;
+    }
+    // FluxBand (Fluxes.jl:170-215): band b owns the rows [bnd_lo/16, (bnd_lo + bnd_ng)/16); scaled like
+    // the broadband fluxes (Fluxes.jl:448-454), net from the scaled values (update_fluxes.jl:198-201)
+    if (fl.band_up) {
+        for (int i = threadIdx.x; i < d.nbnd * nlev; i += blockDim.x) {
+            const int b = i / nlev, lev = i - b * nlev;
+            FT up = FT(0), dn = FT(0);
+            if (!zero) {
+                const int r0 = lk.bnd_lo[b] >> 4, r1 = (lk.bnd_lo[b] + lk.bnd_ng[b]) >> 4;
+                for (int r = r0; r < r1; r++) {
+                    up += sh.acc[((size_t)r * nlev + lev) * d.n_acc];
+                    dn += sh.acc[((size_t)r * nlev + lev) * d.n_acc + 1];
+                }
+            }
+            if (fl.metric) {
+                const FT m = fl.metric[(size_t)nlev * col + lev];
+                up *= m; dn *= m;
+            }
+            const size_t o = ((size_t)b * ncol + col) * nlev + lev;
+            fl.band_up[o] = up; fl.band_dn[o] = dn;
+            if (fl.band_net) fl.band_net[o] = up - dn;
+        }
     }
 }
 

@@ -84,7 +84,7 @@ __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColSh
 
 constexpr int DB = 8;  // levels per batch of the top-down sweeps
 
-template <typename FT, bool TWOSTREAM>
+template <typename FT, bool TWOSTREAM, bool BAND>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
         }
         const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
         const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)ncol * g] : FT(0);
-        FT *acc = sh.acc + (size_t)wave * nlev * d.n_acc;
+        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * d.n_acc;
+        const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
 
         if (TWOSTREAM) {
@@ -130,8 +131,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                 sw.at(kl, 0) = Tdif * denom;                         // A
                 sw.at(kl, 1) = (Rdif * src + src_dn) * denom;        // B
                 sw.at(kl, 2) = albedo;
-                const FT ss = wave_sum_to_lane63(src * amask);
-                if (lane == 63) acc[kl * 2] = ss;
+                const FT ss = seg_sum<BAND>(src * amask);
+                if (writer) acc[kl * 2] = ss;
                 const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
                 src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
                 albedo = albedo_n;
@@ -166,8 +167,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
             FT F = inc;
             {
-                const FT su = wave_sum_to_lane63((F * albedo + src) * amask), sd = wave_sum_to_lane63(F * amask);
-                if (lane == 63) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
+                const FT su = seg_sum<BAND>((F * albedo + src) * amask), sd = seg_sum<BAND>(F * amask);
+                if (writer) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
             }
             for (int kh = nlay - 1; kh >= 0; kh -= DB) {
                 // DB levels per batch: all scratch loads are issued before the dependent FMA chain
@@ -182,8 +183,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                     if (kh - j >= 0) {
                         const int k = kh - j;
                         F = A[j] * F + B[j];
-                        const FT su = wave_sum_to_lane63(F * AL[j] * amask), sd = wave_sum_to_lane63(F * amask);
-                        if (lane == 63) { acc[k * 2] += su; acc[k * 2 + 1] = sd; }
+                        const FT su = seg_sum<BAND>(F * AL[j] * amask), sd = seg_sum<BAND>(F * amask);
+                        if (writer) { acc[k * 2] += su; acc[k * 2 + 1] = sd; }
                     }
                 }
             }
@@ -225,8 +226,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                 FT I = a.inc_flux ? inc / Num<FT>::pi() : FT(0);
                 const bool first = imu == 0;
                 {
-                    const FT sd = wave_sum_to_lane63(I * i2f * amask);
-                    if (lane == 63) acc[nlay * 2 + 1] = first ? sd : acc[nlay * 2 + 1] + sd;
+                    const FT sd = seg_sum<BAND>(I * i2f * amask);
+                    if (writer) acc[nlay * 2 + 1] = first ? sd : acc[nlay * 2 + 1] + sd;
                 }
                 for (int k = nlay - 1; k >= 0; k--) {
                     const FT tau_loc = sw.at(k, 0) * Ds;
@@ -236,13 +237,13 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
                     I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT sd = wave_sum_to_lane63(I * i2f * amask);
-                    if (lane == 63) acc[k * 2 + 1] = first ? sd : acc[k * 2 + 1] + sd;
+                    const FT sd = seg_sum<BAND>(I * i2f * amask);
+                    if (writer) acc[k * 2 + 1] = first ? sd : acc[k * 2 + 1] + sd;
                 }
                 I = I * (FT(1) - emis) + emis * sfc_source;
                 {
-                    const FT su = wave_sum_to_lane63(I * i2f * amask);
-                    if (lane == 63) acc[0] = first ? su : acc[0] + su;
+                    const FT su = seg_sum<BAND>(I * i2f * amask);
+                    if (writer) acc[0] = first ? su : acc[0] + su;
                 }
                 for (int lev = 1; lev <= nlay; lev++) {
                     const FT tau_loc = sw.at(lev - 1, 0) * Ds;
@@ -252,13 +253,13 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
                     I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT su = wave_sum_to_lane63(I * i2f * amask);
-                    if (lane == 63) acc[lev * 2] = first ? su : acc[lev * 2] + su;
+                    const FT su = seg_sum<BAND>(I * i2f * amask);
+                    if (writer) acc[lev * 2] = first ? su : acc[lev * 2] + su;
                 }
             }
         }
         __syncthreads();
-        store_column(a.fl, sh, d, col, ncol, false);
+        store_column(a.fl, sh, d, col, ncol, false, a.lk);
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
@@ -297,10 +298,14 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
     RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
+    if (fl.band_up) {
+        RR_CHECK(twostream && fl.band_dn, "per-band fluxes need a two-stream solver and both up/dn buffers");
+        if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
+    }
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
-    d.nwaves = threads / 64; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
+    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 2; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
@@ -315,7 +320,8 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
-    auto kern = twostream ? lw_solve_kernel<FT, true> : lw_solve_kernel<FT, false>;
+    auto kern = !twostream ? lw_solve_kernel<FT, false, false>
+                : fl.band_up ? lw_solve_kernel<FT, true, true> : lw_solve_kernel<FT, true, false>;
     RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);

@@ -76,7 +76,7 @@ struct SwArgs {
 
 constexpr int DB = 8;  // levels per batch of the light sweeps
 
-template <typename FT, bool TWOSTREAM>
+template <typename FT, bool TWOSTREAM, bool BAND>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
@@ -98,18 +98,19 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
         const FT mu0 = a.cos_zenith[col];
         const bool day = mu0 > FT(0);
         if (!TWOSTREAM && !day) {  // shortwave_noscat.jl:86-99: nothing runs for night columns
-            store_column(a.fl, sh, d, col, ncol, true);
+            store_column(a.fl, sh, d, col, ncol, true, a.lk);
             continue;
         }
         prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
-        FT *acc = sh.acc + (size_t)wave * nlev * d.n_acc;
+        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * d.n_acc;
+        const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
 
         if (!TWOSTREAM) {
             // rte_sw_noscat!, shortwave_noscat.jl:120-148 (multiplicative Beer-Lambert, flux_up = 0)
             FT dir = a.toa_flux[col] * solar_frac * mu0;
             {
-                const FT s = wave_sum_to_lane63(dir * amask);
-                if (lane == 63) { acc[nlay * 3] = FT(0); acc[nlay * 3 + 1] = s; acc[nlay * 3 + 2] = s; }
+                const FT s = seg_sum<BAND>(dir * amask);
+                if (writer) { acc[nlay * 3] = FT(0); acc[nlay * 3 + 1] = s; acc[nlay * 3 + 2] = s; }
             }
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
@@ -121,12 +122,12 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                     FT tau, ssa, pf;
                     gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
                     dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
-                    const FT s = wave_sum_to_lane63(dir * amask);
-                    if (lane == 63) { acc[k * 3] = FT(0); acc[k * 3 + 1] = s; acc[k * 3 + 2] = s; }
+                    const FT s = seg_sum<BAND>(dir * amask);
+                    if (writer) { acc[k * 3] = FT(0); acc[k * 3 + 1] = s; acc[k * 3 + 2] = s; }
                 }
             }
             __syncthreads();
-            store_column(a.fl, sh, d, col, ncol, false);
+            store_column(a.fl, sh, d, col, ncol, false, a.lk);
             __syncthreads();
             continue;
         }
@@ -156,8 +157,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             FT tau_cum = FT(0), dir_above = dir_top;
             FT beta = FT(0), delta = FT(0);
             {
-                const FT s = wave_sum_to_lane63(dir_top * amask);
-                if (lane == 63) { acc[nlay * 3 + 2] = s; acc[nlay * 3 + 1] = FT(0); }
+                const FT s = seg_sum<BAND>(dir_top * amask);
+                if (writer) { acc[nlay * 3 + 2] = s; acc[nlay * 3 + 1] = FT(0); }
             }
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
@@ -182,8 +183,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                     const FT beta_n = Rdif + Tdif * Tdif * beta * den;
                     delta = s_dn + Tdif * den * (delta + beta * s_up);
                     beta = beta_n;
-                    const FT sdir = wave_sum_to_lane63(dir_k * amask), sdel = wave_sum_to_lane63(delta * amask);
-                    if (lane == 63) { acc[k * 3 + 2] = sdir; acc[k * 3 + 1] = sdel; }
+                    const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(delta * amask);
+                    if (writer) { acc[k * 3 + 2] = sdir; acc[k * 3 + 1] = sdel; }
                     dir_above = dir_k;
                 }
             }
@@ -192,8 +193,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             const FT sfc_src = dir_above * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
             FT U = m_div(alb * delta + sfc_src, FT(1) - alb * beta);
             {
-                const FT su = wave_sum_to_lane63(U * amask), sb = wave_sum_to_lane63(beta * U * amask);
-                if (lane == 63) { acc[0] = su; acc[1] = (acc[1] + sb) + acc[2]; }
+                const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(beta * U * amask);
+                if (writer) { acc[0] = su; acc[1] = (acc[1] + sb) + acc[2]; }
             }
             // ---- sweep 2, bottom-up: fluxes ----
             for (int kl = 0; kl < nlay; kl += DB) {
@@ -208,8 +209,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                     if (kl + j < nlay) {
                         const int lev = kl + j + 1;
                         U = A[j] * U + B[j];
-                        const FT su = wave_sum_to_lane63(U * amask), sb = wave_sum_to_lane63(BE[j] * U * amask);
-                        if (lane == 63) { acc[lev * 3] = su; acc[lev * 3 + 1] = (acc[lev * 3 + 1] + sb) + acc[lev * 3 + 2]; }
+                        const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
+                        if (writer) { acc[lev * 3] = su; acc[lev * 3 + 1] = (acc[lev * 3 + 1] + sb) + acc[lev * 3 + 2]; }
                     }
                 }
             }
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             a.as.aod_sw_ext[col] = e;
             a.as.aod_sw_sca[col] = s;
         }
-        store_column(a.fl, sh, d, col, ncol, !day);
+        store_column(a.fl, sh, d, col, ncol, !day, a.lk);
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
@@ -260,7 +261,11 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
     RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
-    d.nwaves = threads / 64; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
+    if (fl.band_up) {
+        RR_CHECK(twostream && fl.band_dn, "per-band fluxes need a two-stream solver and both up/dn buffers");
+        if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
+    }
+    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
@@ -271,7 +276,8 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
-    auto kern = twostream ? sw_solve_kernel<FT, true> : sw_solve_kernel<FT, false>;
+    auto kern = !twostream ? sw_solve_kernel<FT, false, false>
+                : fl.band_up ? sw_solve_kernel<FT, true, true> : sw_solve_kernel<FT, true, false>;
     RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);

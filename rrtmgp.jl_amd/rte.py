@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _abi, _lib
 from .lookups import GasLookup, LookUpAerosolMerra, LookUpCld
-from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, SwBCs, array_dtype, array_ptr,
+from .states import (AtmosphericState, Flux, FluxBand, GrayAtmosphericState, LwBCs, SwBCs, array_dtype, array_ptr,
                      julia_shape)
 
 
@@ -112,11 +112,18 @@ class _RTE:
     sw = False
 
     def __init__(self, ncol, nlay, dtype, bcs, device=0, flux_device=None, layout=_abi.LAYOUT_NLEV_NCOL,
-                 n_gauss_angles=1, workspace: Optional[Workspace] = None):
+                 n_gauss_angles=1, workspace: Optional[Workspace] = None, n_bnd_band_flux: int = 0):
+        """`n_bnd_band_flux` > 0 allocates the optional FluxBand (RTE.jl:106,127,224,245);
+        only the two-stream workspaces carry one."""
         self.bcs = bcs
         self.n_gauss_angles = n_gauss_angles
         self.ws = workspace or Workspace(ncol, nlay, dtype, device)
         self.flux = Flux.allocate(ncol, nlay + 1, dtype, sw=self.sw, layout=layout, device=flux_device)
+        self.band_flux = None
+        if n_bnd_band_flux:
+            if not self.twostream:
+                raise ValueError("spectral fluxes require a two-stream, non-gray solver (getters.jl:404)")
+            self.band_flux = FluxBand.allocate(ncol, nlay + 1, n_bnd_band_flux, dtype, device=flux_device)
 
     @property
     def device(self):
@@ -148,7 +155,7 @@ def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=
     """solve_lw! (RTESolver.jl:33,54,77,117).  Gray when `as_` is a GrayAtmosphericState."""
     L = _lib.lib()
     o = _opts(slv.n_gauss_angles, metric_scaling, seed, col_offset)
-    db, df = slv.bcs.desc(), slv.flux.desc()
+    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux)
     if isinstance(as_, GrayAtmosphericState):
         if slv.n_gauss_angles != 1:
             raise ValueError("gray radiation is solved with a single quadrature angle")
@@ -169,7 +176,7 @@ def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=
     """solve_sw! (RTESolver.jl:151,167,188,222)."""
     L = _lib.lib()
     o = _opts(1, metric_scaling, seed, col_offset)
-    db, df = slv.bcs.desc(), slv.flux.desc()
+    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux)
     if isinstance(as_, GrayAtmosphericState):
         dg = as_.desc()
         fn = L.rrtmgp_hip_rte_sw_2stream_solve_gray if slv.twostream else L.rrtmgp_hip_rte_sw_noscat_solve_gray

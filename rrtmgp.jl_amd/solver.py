@@ -64,7 +64,8 @@ class RRTMGPSolver:
 
     def __init__(self, radiation_method, params: RRTMGPParameters, bcs_lw: LwBCs, bcs_sw: SwBCs, as_,
                  op_lw: str = "twostream", op_sw: str = "twostream", deep_atmosphere_inverse_scaling=None,
-                 lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0):
+                 lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0,
+                 spectral_fluxes: bool = False):
         self.radiation_method, self.params, self.as_ = radiation_method, params, as_
         self.deep_atmosphere_inverse_scaling = deep_atmosphere_inverse_scaling
         gray = isinstance(radiation_method, GrayRadiation)
@@ -81,6 +82,11 @@ class RRTMGPSolver:
                              "shortwave radiation requires scattering.")
         if not gray and lookups is None:
             raise ValueError("spectral radiation needs `lookups` (the NetCDF loader is outside this back end)")
+        if spectral_fluxes:   # solver.jl:252-258
+            if gray:
+                raise ValueError("spectral_fluxes = true is not supported for GrayRadiation (a single band).")
+            if op_lw == "onescalar" or op_sw == "onescalar":
+                raise ValueError("spectral_fluxes = true requires two-stream optics for both bands.")
         self.lookups = lookups or LookupBundle()
         nlay, ncol = as_.dims
         dtype = as_.dtype
@@ -89,8 +95,11 @@ class RRTMGPSolver:
         lw_cls = rte.TwoStreamLWRTE if op_lw == "twostream" else rte.NoScatLWRTE
         sw_cls = rte.TwoStreamSWRTE if op_sw == "twostream" else rte.NoScatSWRTE
         # compute buffers ARE the (nlev, ncol) presentation: update_presentation! is a no-op here
-        self.lws = lw_cls(ncol, nlay, dtype, bcs_lw, n_gauss_angles=n_gauss_angles, workspace=ws)
-        self.sws = sw_cls(ncol, nlay, dtype, bcs_sw, workspace=ws)
+        nb_lw = self.lookups.lookup_lw.n_bnd if spectral_fluxes else 0
+        nb_sw = self.lookups.lookup_sw.n_bnd if spectral_fluxes else 0
+        self.lws = lw_cls(ncol, nlay, dtype, bcs_lw, n_gauss_angles=n_gauss_angles, workspace=ws,
+                          n_bnd_band_flux=nb_lw)
+        self.sws = sw_cls(ncol, nlay, dtype, bcs_sw, workspace=ws, n_bnd_band_flux=nb_sw)
         self.net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F")
         diag = isinstance(radiation_method, AllSkyRadiationWithClearSkyDiagnostics)
         self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False) if diag else None
@@ -182,6 +191,25 @@ def sw_flux_dn(s): return s.sws.flux.flux_dn
 def sw_flux_net(s): return s.sws.flux.flux_net
 def sw_direct_flux_dn(s): return s.sws.flux.flux_dn_dir
 def net_flux(s): return s.net_flux_buffer
+
+
+def _solver_band_flux(ws):   # getters.jl:398-404
+    if not ws.twostream:
+        raise ValueError("spectral fluxes require a two-stream, non-gray solver.")
+    if ws.band_flux is None:
+        raise ValueError("spectral fluxes were not retained; construct the `RRTMGPSolver` with "
+                         "`spectral_fluxes = true`.")
+    return ws.band_flux
+
+
+def spectral_lw_flux_up(s): return _solver_band_flux(s.lws).flux_up
+def spectral_lw_flux_dn(s): return _solver_band_flux(s.lws).flux_dn
+def spectral_lw_flux_net(s): return _solver_band_flux(s.lws).flux_net
+def spectral_sw_flux_up(s): return _solver_band_flux(s.sws).flux_up
+def spectral_sw_flux_dn(s): return _solver_band_flux(s.sws).flux_dn
+def spectral_sw_flux_net(s): return _solver_band_flux(s.sws).flux_net
+def lw_band_bounds(s): return s.lookups.lookup_lw.bnd_lims_wn
+def sw_band_bounds(s): return s.lookups.lookup_sw.bnd_lims_wn
 def clear_lw_flux_up(s): return s.clear_flux_lw.flux_up
 def clear_lw_flux_dn(s): return s.clear_flux_lw.flux_dn
 def clear_lw_flux_net(s): return s.clear_flux_lw.flux_net

@@ -222,10 +222,17 @@ class Flux(_Container):
             arrs = [torch.full(tuple(reversed(shape)), float("nan"), dtype=tdt, device=device) for _ in range(n)]
         return Flux(arrs[0], arrs[1], arrs[2], arrs[3] if sw else None, layout)
 
-    def desc(self) -> _abi.FluxOut:
+    def desc(self, band: "FluxBand" = None) -> _abi.FluxOut:
         d = _abi.FluxOut()
         mems = set()
         self._set_ptrs(d, ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"), mems)
+        if band is not None:
+            for n in ("flux_up", "flux_dn", "flux_net"):
+                p, m = array_ptr(getattr(band, n))
+                setattr(d, "band_" + n, p)
+                mems.add(m)
+        if len(mems) != 1:
+            raise ValueError("flux buffers must all live in the same memory space")
         d.mem = mems.pop()
         d.layout = self.layout
         return d
@@ -234,6 +241,25 @@ class Flux(_Container):
         """Host copy of one flux array indexed [ilev, icol] whatever the storage layout."""
         a = to_host(getattr(self, name))
         return a if self.layout == _abi.LAYOUT_NLEV_NCOL else np.asfortranarray(a.T)
+
+
+@dataclass
+class FluxBand(_Container):
+    """Optional per-band fluxes (nlev, ncol, n_bnd), src/optics/Fluxes.jl:170-186."""
+    flux_up: object
+    flux_dn: object
+    flux_net: object
+
+    @staticmethod
+    def allocate(ncol, nlev, n_bnd, dtype, device=None):
+        shape = (nlev, ncol, n_bnd)
+        if device is None:
+            arrs = [np.full(shape, np.nan, dtype=dtype, order="F") for _ in range(3)]
+        else:
+            import torch
+            tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(dtype)]
+            arrs = [torch.full(tuple(reversed(shape)), float("nan"), dtype=tdt, device=device) for _ in range(3)]
+        return FluxBand(*arrs)
 
 
 @dataclass
