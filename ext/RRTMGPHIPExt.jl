@@ -111,8 +111,15 @@ struct ParamsDesc
     kappa_d::Float64; stefan::Float64; avogad::Float64
 end
 
+struct PrepareOpts
+    steps::Int32; interpolation::Int32; bottom_extrapolation::Int32; isothermal_boundary_layer::Int32
+    z_mem::Int32; idx_h2o::Int32
+    center_z::P; face_z::P
+    p_min::Float64; t_min::Float64; t_max::Float64
+end
+
 const ABI_STRUCTS = (MinorDesc, GasLookupDesc, CloudLookupDesc, AerosolLookupDesc, AtmosStateDesc, LwBcsDesc,
-                     SwBcsDesc, FluxOutDesc, SolveOpts, GrayStateDesc, ParamsDesc)
+                     SwBcsDesc, FluxOutDesc, SolveOpts, GrayStateDesc, ParamsDesc, PrepareOpts)
 
 function __init__()
     libhip[] = get(ENV, "RRTMGP_HIP_LIBRARY", libhip[])
@@ -376,6 +383,31 @@ function compute_relative_humidity!(dev::HIPDevice, rh::AbstractArray{FT, 2}, p_
         (:rrtmgp_hip_compute_relative_humidity, libhip[]), Cint, (P, Int32, P, P, P, Ref{ParamsDesc}, P),
         workspace(dev, ncol, nlay, FT), 0, ptr(r), ptr(p), ptr(t), params_desc(param_set), ptr(h)))
     r === rh || copyto!(rh, r)
+    return nothing
+end
+
+# prepare_atmosphere! (src/api/update_fluxes.jl:252-281) as one launch instead of the broadcast
+# cascade of src/api/grid_adaptation.jl.  Optional: with `array_type(::HIPDevice) = Array` the
+# reference's own host cascade also works; a host model calls this instead to save those passes.
+const INTERP_CODE = Dict(:NoInterpolation => 0, :ArithmeticMean => 1, :GeometricMean => 2, :UniformZ => 3,
+                         :UniformP => 4, :BestFit => 5)
+const BOTTOM_CODE = Dict(:SameAsInterpolation => 0, :UseSurfaceTempAtBottom => 1, :HydrostaticBottom => 2)
+
+function hip_prepare_atmosphere!(dev::HIPDevice, as::AtmosphericState, param_set::RP.ARP, lookup_lw::LookUpLW;
+                                 interpolation = RRTMGP.NoInterpolation(),
+                                 bottom_extrapolation = RRTMGP.SameAsInterpolation(),
+                                 isothermal_boundary_layer::Bool = false, center_z = nothing, face_z = nothing)
+    FT = eltype(as.p_lev)
+    nlay, ncol = size(as.layerdata, 2), size(as.layerdata, 3)
+    icode = INTERP_CODE[nameof(typeof(interpolation))]
+    steps = icode == 0 ? Int32(14) : Int32(15)  # RRTMGP_PREP_ALL without / with INTERPOLATE
+    o = PrepareOpts(steps, icode, BOTTOM_CODE[nameof(typeof(bottom_extrapolation))], isothermal_boundary_layer, 0,
+                    lookup_lw.idx_h2o, ptr(center_z), ptr(face_z), lookup_lw.p_ref_min, lookup_lw.t_ref_min,
+                    lookup_lw.t_ref_max)
+    GC.@preserve as center_z face_z check(ccall(
+        (:rrtmgp_hip_prepare_atmosphere, libhip[]), Cint, (P, Ref{AtmosStateDesc}, Ref{ParamsDesc}, Ref{PrepareOpts}),
+        workspace(dev, ncol, nlay, FT), state_desc(as, !isnothing(as.cloud_state), !isnothing(as.aerosol_state)),
+        params_desc(param_set), o))
     return nothing
 end
 

@@ -326,6 +326,54 @@ int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_
 int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
                                          const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o);
 
+/* prepare_atmosphere!(s::RRTMGPSolver)  src/api/update_fluxes.jl:252-281 — the whole
+ * preparation cascade of src/api/grid_adaptation.jl, in place, one kernel, columns independent:
+ *   RRTMGP_PREP_INTERPOLATE  interpolate_levels! (:73-113): interior faces and the top face by
+ *                            `interpolation`, the bottom face by `bottom_extrapolation`
+ *                            (formulas: src/api/interpolation.jl:176-252);
+ *   RRTMGP_PREP_ISOTHERMAL   add_isothermal_boundary_layer! (:137-173): the state's LAST layer
+ *                            is the extra layer (interpolation then covers nlay - 1 layers);
+ *   RRTMGP_PREP_CLIP         clip! (:232-258): vmr_h2o >= 0, p >= p_min, T in [t_min, t_max]
+ *                            (t_min > t_max skips the temperature clamp);
+ *   RRTMGP_PREP_COL_DRY      update_concentrations! (:278-292) = compute_col_gas!.
+ * Every array of `as` named below is read AND written (the const in rrtmgp_atmos_state is
+ * cast away): layerdata, p_lev, t_lev, vmr_h2o / vmr_o3 / vmr, cloud and aerosol inputs. */
+#define RRTMGP_PREP_INTERPOLATE 1
+#define RRTMGP_PREP_ISOTHERMAL 2
+#define RRTMGP_PREP_CLIP 4
+#define RRTMGP_PREP_COL_DRY 8
+#define RRTMGP_PREP_ALL 15
+
+#define RRTMGP_INTERP_NONE 0            /* NoInterpolation, interpolation.jl:47 */
+#define RRTMGP_INTERP_ARITHMETIC_MEAN 1 /* :55 */
+#define RRTMGP_INTERP_GEOMETRIC_MEAN 2  /* :64 */
+#define RRTMGP_INTERP_UNIFORM_Z 3       /* :73 */
+#define RRTMGP_INTERP_UNIFORM_P 4       /* :82 */
+#define RRTMGP_INTERP_BEST_FIT 5        /* :90, needs center_z / face_z */
+
+#define RRTMGP_BOTTOM_SAME_AS_INTERPOLATION 0 /* :119 */
+#define RRTMGP_BOTTOM_USE_SURFACE_TEMP 1      /* :128 */
+#define RRTMGP_BOTTOM_HYDROSTATIC 2           /* :136, needs center_z / face_z */
+
+typedef struct rrtmgp_prepare_opts {
+    int32_t steps;                     /* OR of RRTMGP_PREP_* */
+    int32_t interpolation;             /* RRTMGP_INTERP_* */
+    int32_t bottom_extrapolation;      /* RRTMGP_BOTTOM_* */
+    int32_t isothermal_boundary_layer; /* grid has the extra top layer (also shortens the interpolation) */
+    int32_t z_mem;                     /* mem kind of center_z / face_z */
+    int32_t idx_h2o;                   /* 1-based row of h2o in a FULL vmr */
+    const void *center_z;              /* FT (nlay, ncol) or NULL */
+    const void *face_z;                /* FT (nlev, ncol) or NULL */
+    double p_min, t_min, t_max;
+} rrtmgp_prepare_opts;
+
+int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_params *params,
+                                  const rrtmgp_prepare_opts *opts);
+/* Gray state: interpolation, isothermal layer (p, T only) and the pressure clip
+ * (grid_adaptation.jl:147-156, 215-227); col_dry does not exist. */
+int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
+                                       const rrtmgp_params *params, const rrtmgp_prepare_opts *opts);
+
 /* ---- McICA stream -------------------------------------------------------- */
 
 /* The reference draws Random.rand() (Float64) per (g-point, column) inside

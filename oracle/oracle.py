@@ -128,6 +128,23 @@ def solve_sw_gray(gs, bcs, twostream=True, metric_scaling=None, layout=_abi.LAYO
     return flux
 
 
+def prepare_atmosphere(as_, params, steps=_abi.PREP_ALL, **kw):
+    """The prepare_atmosphere! cascade on host arrays, in place; `kw` as
+    rrtmgp_jl_amd.grid_adaptation.make_prepare_opts."""
+    from rrtmgp_jl_amd.grid_adaptation import make_prepare_opts
+    from rrtmgp_jl_amd.states import GrayAtmosphericState
+    o, pd = make_prepare_opts(steps, **kw), params.desc()
+    if isinstance(as_, GrayAtmosphericState):
+        d = as_.desc()
+        _check(lib().rrtmgp_oracle_prepare_atmosphere_gray(_abi.ftype_of(as_.dtype), C.byref(d), C.byref(pd),
+                                                           C.byref(o)), "prepare_atmosphere_gray")
+    else:
+        d = as_.desc()
+        _check(lib().rrtmgp_oracle_prepare_atmosphere(_abi.ftype_of(as_.dtype), C.byref(d), C.byref(pd), C.byref(o)),
+               "prepare_atmosphere")
+    return as_
+
+
 def compute_col_gas(p_lev, params, vmr_h2o=None, lat=None):
     nlev, ncol = p_lev.shape
     col_dry = np.empty((nlev - 1, ncol), dtype=p_lev.dtype, order="F")

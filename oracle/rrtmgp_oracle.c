@@ -142,6 +142,16 @@ int rrtmgp_oracle_rte_sw_noscat_solve_gray(const rrtmgp_gray_state *as, const rr
     return DISPATCH(ftype, solve_sw_gray_f32(0, as, bcs, flux, opts), solve_sw_gray_f64(0, as, bcs, flux, opts));
 }
 
+int rrtmgp_oracle_prepare_atmosphere(int32_t ftype, const rrtmgp_atmos_state *as, const rrtmgp_params *params,
+                                     const rrtmgp_prepare_opts *opts) {
+    return DISPATCH(ftype, prepare_atmosphere_as_f32(as, params, opts), prepare_atmosphere_as_f64(as, params, opts));
+}
+int rrtmgp_oracle_prepare_atmosphere_gray(int32_t ftype, const rrtmgp_gray_state *as, const rrtmgp_params *params,
+                                          const rrtmgp_prepare_opts *opts) {
+    return DISPATCH(ftype, prepare_atmosphere_gray_f32(as, params, opts),
+                    prepare_atmosphere_gray_f64(as, params, opts));
+}
+
 int rrtmgp_oracle_compute_col_gas(int32_t ftype, int64_t ncol, int64_t nlay, const void *p_lev, void *col_dry,
                                   const rrtmgp_params *params, const void *vmr_h2o, const void *lat) {
     if (ftype == RRTMGP_F32)

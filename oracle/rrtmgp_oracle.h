@@ -53,6 +53,13 @@ int rrtmgp_oracle_rte_sw_2stream_solve_gray(const rrtmgp_gray_state *as, const r
 int rrtmgp_oracle_rte_sw_noscat_solve_gray(const rrtmgp_gray_state *as, const rrtmgp_sw_bcs *bcs,
                                            const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts, int32_t ftype);
 
+/* prepare_atmosphere! cascade, src/api/grid_adaptation.jl:73-292 + interpolation.jl:148-252; in place.
+ * `ftype` is needed because the state structs do not carry it. */
+int rrtmgp_oracle_prepare_atmosphere(int32_t ftype, const rrtmgp_atmos_state *as, const rrtmgp_params *params,
+                                     const rrtmgp_prepare_opts *opts);
+int rrtmgp_oracle_prepare_atmosphere_gray(int32_t ftype, const rrtmgp_gray_state *as, const rrtmgp_params *params,
+                                          const rrtmgp_prepare_opts *opts);
+
 /* prep: src/optics/column_amounts.jl */
 int rrtmgp_oracle_compute_col_gas(int32_t ftype, int64_t ncol, int64_t nlay, const void *p_lev, void *col_dry,
                                   const rrtmgp_params *params, const void *vmr_h2o, const void *lat);

@@ -86,6 +86,17 @@ class Params(C.Structure):
                 ("kappa_d", f64), ("stefan", f64), ("avogad", f64)]
 
 
+class PrepareOpts(C.Structure):
+    _fields_ = [("steps", i32), ("interpolation", i32), ("bottom_extrapolation", i32),
+                ("isothermal_boundary_layer", i32), ("z_mem", i32), ("idx_h2o", i32), ("center_z", vp),
+                ("face_z", vp), ("p_min", f64), ("t_min", f64), ("t_max", f64)]
+
+
+PREP_INTERPOLATE, PREP_ISOTHERMAL, PREP_CLIP, PREP_COL_DRY, PREP_ALL = 1, 2, 4, 8, 15
+INTERP = {"none": 0, "arithmetic_mean": 1, "geometric_mean": 2, "uniform_z": 3, "uniform_p": 4, "best_fit": 5}
+BOTTOM = {"same_as_interpolation": 0, "use_surface_temp_at_bottom": 1, "hydrostatic_bottom": 2}
+
+
 def ftype_of(dtype) -> int:
     dtype = np.dtype(dtype)
     if dtype == np.float32:

@@ -44,6 +44,10 @@ EXPORTS = {
                                                       C.POINTER(_abi.SolveOpts)]),
     "rrtmgp_hip_compute_col_gas": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(_abi.Params), _P, _P]),
     "rrtmgp_hip_compute_relative_humidity": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(_abi.Params), _P]),
+    "rrtmgp_hip_prepare_atmosphere": (C.c_int, [_P, C.POINTER(_abi.AtmosState), C.POINTER(_abi.Params),
+                                                C.POINTER(_abi.PrepareOpts)]),
+    "rrtmgp_hip_prepare_atmosphere_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), C.POINTER(_abi.Params),
+                                                     C.POINTER(_abi.PrepareOpts)]),
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rrtmgp_hip_version": (C.c_char_p, []),
@@ -51,7 +55,7 @@ EXPORTS = {
 }
 
 ABI_STRUCTS = [_abi.MinorDesc, _abi.GasLookupDesc, _abi.CloudLookupDesc, _abi.AerosolLookupDesc, _abi.AtmosState,
-               _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params]
+               _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params, _abi.PrepareOpts]
 
 
 class RRTMGPHipError(RuntimeError):

@@ -271,7 +271,7 @@ static int select_device(int device) {
 enum Slot {
     S_LAYERDATA = 0, S_TLEV, S_TSFC, S_VMR_H2O, S_VMR_O3, S_VMR, S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F,
     S_CLD_COVER, S_AERO_SIZE, S_AERO_MASS, S_AOD_EXT, S_AOD_SCA, S_BC0, S_BC1, S_BC2, S_BC3, S_FLUX_UP, S_FLUX_DN,
-    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_NSLOTS
+    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_ZC, S_ZF, S_NSLOTS
 };
 
 struct Stager {
@@ -295,6 +295,16 @@ struct Stager {
         TRY(stage_ensure(ws, slot, bytes));
         *outp = ws->stage[slot].ptr;
         backs.push_back({p, ws->stage[slot].ptr, bytes});
+        return RRTMGP_OK;
+    }
+    // read AND written: staged in, copied back by finish()
+    int inout(int mem, int slot, const void *p, size_t bytes, void **outp) {
+        if (!p) { *outp = nullptr; return RRTMGP_OK; }
+        if (mem == RRTMGP_MEM_DEVICE) { *outp = const_cast<void *>(p); return RRTMGP_OK; }
+        TRY(stage_ensure(ws, slot, bytes));
+        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, ws->stream));
+        *outp = ws->stage[slot].ptr;
+        backs.push_back({const_cast<void *>(p), ws->stage[slot].ptr, bytes});
         return RRTMGP_OK;
     }
     int finish() {
@@ -441,6 +451,67 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl, twostream ? (size_t)lk.n_bnd : 0));
     TRY(launch_sw<FT>(ws, twostream, lk, cld, aero, ds, mu0, toa, adir, adif, fl, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
+    return st.finish();
+}
+
+// prepare_atmosphere! (update_fluxes.jl:252-281): stage every array the cascade touches as in/out
+template <typename FT>
+static int prepare_t(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_params *ps,
+                     const rrtmgp_prepare_opts *o) {
+    const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1, n2 = nlay * ncol * E;
+    RR_CHECK(as->layerdata && as->p_lev && as->t_lev && as->t_sfc, "prepare_atmosphere: missing array");
+    Stager st{ws, {}};
+    PrepView<FT> v{};
+    v.ncol = (int)ncol; v.nlay = (int)nlay; v.ls = 4;
+    const int mem = as->mem;
+    FT *ld;
+    TRY(st.inout(mem, S_LAYERDATA, as->layerdata, 4 * n2, (void **)&ld));
+    v.col_dry = ld; v.p_lay = ld + 1; v.t_lay = ld + 2; v.rel_hum = ld + 3;
+    TRY(st.inout(mem, S_PLEV, as->p_lev, nlev * ncol * E, (void **)&v.p_lev));
+    TRY(st.inout(mem, S_TLEV, as->t_lev, nlev * ncol * E, (void **)&v.t_lev));
+    TRY(st.in(mem, S_TSFC, as->t_sfc, ncol * E, (const void **)&v.t_sfc));
+    TRY(st.in(mem, S_LAT, as->lat, ncol * E, (const void **)&v.lat));
+    if (as->vmr_kind == RRTMGP_VMR_GM) {
+        RR_CHECK(as->vmr_h2o, "VmrGM: vmr_h2o is required");
+        TRY(st.inout(mem, S_VMR_H2O, as->vmr_h2o, n2, (void **)&v.vmr_h2o));
+        TRY(st.inout(mem, S_VMR_O3, as->vmr_o3, n2, (void **)&v.vmr_o3));
+        v.hs = 1;
+    } else {
+        RR_CHECK(as->vmr && o->idx_h2o >= 1 && o->idx_h2o <= as->ngas, "Vmr: idx_h2o out of range");
+        TRY(st.inout(mem, S_VMR, as->vmr, (size_t)as->ngas * n2, (void **)&v.vmr_full));
+        v.ngas = (int)as->ngas; v.hs = (int)as->ngas; v.vmr_h2o = v.vmr_full + (o->idx_h2o - 1);
+    }
+    if ((o->steps & RRTMGP_PREP_ISOTHERMAL) && o->isothermal_boundary_layer) {
+        const void *cl[5] = {as->cld_r_eff_liq, as->cld_r_eff_ice, as->cld_path_liq, as->cld_path_ice, as->cld_frac};
+        const int slot[5] = {S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F};
+        for (int i = 0; i < 5; i++) TRY(st.inout(mem, slot[i], cl[i], n2, (void **)&v.cld[i]));
+        TRY(st.inout(mem, S_AERO_SIZE, as->aero_size, RRTMGP_N_AEROSOLS * n2, (void **)&v.aero[0]));
+        TRY(st.inout(mem, S_AERO_MASS, as->aero_mass, RRTMGP_N_AEROSOLS * n2, (void **)&v.aero[1]));
+    }
+    TRY(st.in(o->z_mem, S_ZC, o->center_z, n2, (const void **)&v.center_z));
+    TRY(st.in(o->z_mem, S_ZF, o->face_z, nlev * ncol * E, (const void **)&v.face_z));
+    TRY(launch_prepare<FT>(ws, v, *ps, *o, false));
+    return st.finish();
+}
+
+template <typename FT>
+static int prepare_gray_t(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const rrtmgp_params *ps,
+                          const rrtmgp_prepare_opts *o) {
+    const size_t E = sizeof(FT), ncol = gs->ncol, nlay = gs->nlay, nlev = nlay + 1;
+    RR_CHECK(gs->p_lay && gs->p_lev && gs->t_lay && gs->t_lev && gs->t_sfc, "prepare_atmosphere (gray): missing array");
+    Stager st{ws, {}};
+    PrepView<FT> v{};
+    v.ncol = (int)ncol; v.nlay = (int)nlay; v.ls = 1;
+    TRY(st.inout(gs->mem, S_PLAY, gs->p_lay, nlay * ncol * E, (void **)&v.p_lay));
+    TRY(st.inout(gs->mem, S_TLAY, gs->t_lay, nlay * ncol * E, (void **)&v.t_lay));
+    TRY(st.inout(gs->mem, S_PLEV, gs->p_lev, nlev * ncol * E, (void **)&v.p_lev));
+    TRY(st.inout(gs->mem, S_TLEV, gs->t_lev, nlev * ncol * E, (void **)&v.t_lev));
+    TRY(st.in(gs->mem, S_TSFC, gs->t_sfc, ncol * E, (const void **)&v.t_sfc));
+    TRY(st.in(o->z_mem, S_ZC, o->center_z, nlay * ncol * E, (const void **)&v.center_z));
+    TRY(st.in(o->z_mem, S_ZF, o->face_z, nlev * ncol * E, (const void **)&v.face_z));
+    rrtmgp_prepare_opts og = *o;
+    og.steps &= ~RRTMGP_PREP_COL_DRY;
+    TRY(launch_prepare<FT>(ws, v, *ps, og, true));
     return st.finish();
 }
 
@@ -730,6 +801,23 @@ int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void
                                    : rel_hum_t<double>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o);
 }
 
+int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_params *params,
+                                  const rrtmgp_prepare_opts *opts) {
+    RR_CHECK(ws && as && params && opts, "null argument");
+    RR_CHECK(as->ncol >= 0 && as->ncol <= ws->ncol && as->nlay == ws->nlay, "state does not fit the workspace");
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? prepare_t<float>(ws, as, params, opts) : prepare_t<double>(ws, as, params, opts);
+}
+
+int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_params *params,
+                                       const rrtmgp_prepare_opts *opts) {
+    RR_CHECK(ws && as && params && opts, "null argument");
+    RR_CHECK(as->ncol >= 0 && as->ncol <= ws->ncol && as->nlay == ws->nlay, "state does not fit the workspace");
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? prepare_gray_t<float>(ws, as, params, opts)
+                                   : prepare_gray_t<double>(ws, as, params, opts);
+}
+
 double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32_t is_sw, int32_t draw) {
     return mcica_draw(mcica_key(seed, gcol, igpt, is_sw), draw);
 }
@@ -756,6 +844,7 @@ int rrtmgp_hip_abi_sizeof(int which) {
         case 8: return (int)sizeof(rrtmgp_solve_opts);
         case 9: return (int)sizeof(rrtmgp_gray_state);
         case 10: return (int)sizeof(rrtmgp_params);
+        case 11: return (int)sizeof(rrtmgp_prepare_opts);
         default: return -1;
     }
 }

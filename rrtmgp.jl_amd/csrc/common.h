@@ -177,4 +177,29 @@ template <typename FT>
 int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p_lay, const FT *t_lay,
                    const rrtmgp_params &ps, const FT *vmr_h2o);
 
+// prepare_atmosphere!: the state through layer / level accessors, so that AtmosphericState
+// (layerdata rows, element stride 4) and GrayAtmosphericState (separate arrays) share one kernel.
+template <typename FT>
+struct PrepView {
+    int ncol, nlay, ls /* element stride of the four layer arrays */;
+    FT *p_lay, *t_lay, *rel_hum, *col_dry;  // element (k, col) at [ls * (k + nlay*col)]
+    FT *p_lev, *t_lev;
+    const FT *t_sfc, *lat;
+    FT *vmr_h2o;  // (k, col) at [hs * (k + nlay*col)]
+    int hs;
+    FT *vmr_o3, *vmr_full;
+    int ngas;
+    FT *cld[5];
+    FT *aero[2];
+    const FT *center_z, *face_z;
+};
+template <typename FT>
+struct PrepArgs {
+    int steps, interpolation, bottom_mode, iso, clamp_t;
+    FT p_min, t_min, t_max, R, cp, g, mol_m_dry, mol_m_h2o, avogadro;
+};
+template <typename FT>
+int launch_prepare(rrtmgp_workspace *ws, const PrepView<FT> &v, const rrtmgp_params &ps, const rrtmgp_prepare_opts &o,
+                   bool gray);
+
 }  // namespace rrtmgp

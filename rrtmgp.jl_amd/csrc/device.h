@@ -56,6 +56,8 @@ __device__ __forceinline__ float m_expm1(float x) { return expm1f(x); }
 __device__ __forceinline__ double m_expm1(double x) { return expm1(x); }
 __device__ __forceinline__ float m_log(float x) { return logf(x); }
 __device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double m_pow(double x, double y) { return pow(x, y); }
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float m_sin(float x) { return sinf(x); }

@@ -7,8 +7,8 @@ reference (`prepare_atmosphere!` -> `update_lw_fluxes!` -> `update_sw_fluxes!` -
 presentation of every flux.  The device work behind it is the C ABI of
 libhip_rrtmgp.so; nothing here computes fluxes.
 
-Scope: `NoInterpolation` only — level interpolation and the isothermal
-boundary layer (src/api/grid_adaptation.jl, interpolation.jl) are the "next" row N2.
+`prepare_atmosphere!` (level interpolation, isothermal boundary layer, clipping, col_dry:
+src/api/grid_adaptation.jl, interpolation.jl) is one device launch, grid_adaptation.py.
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import _abi, rte
+from . import _abi, grid_adaptation, rte
 from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, RRTMGPParameters, SwBCs, VmrGM,
                      array_dtype, to_host)
 
@@ -65,9 +65,17 @@ class RRTMGPSolver:
     def __init__(self, radiation_method, params: RRTMGPParameters, bcs_lw: LwBCs, bcs_sw: SwBCs, as_,
                  op_lw: str = "twostream", op_sw: str = "twostream", deep_atmosphere_inverse_scaling=None,
                  lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0,
-                 spectral_fluxes: bool = False):
+                 spectral_fluxes: bool = False, interpolation: str = grid_adaptation.NoInterpolation,
+                 bottom_extrapolation: str = grid_adaptation.SameAsInterpolation,
+                 isothermal_boundary_layer: bool = False, center_z=None, face_z=None):
         self.radiation_method, self.params, self.as_ = radiation_method, params, as_
         self.deep_atmosphere_inverse_scaling = deep_atmosphere_inverse_scaling
+        self.interpolation, self.bottom_extrapolation = interpolation, bottom_extrapolation
+        self.isothermal_boundary_layer, self.center_z, self.face_z = isothermal_boundary_layer, center_z, face_z
+        if interpolation != grid_adaptation.NoInterpolation and (
+                grid_adaptation.requires_z(interpolation) or grid_adaptation.requires_z(bottom_extrapolation)) and (
+                center_z is None or face_z is None):
+            raise ValueError("BestFit / HydrostaticBottom need `center_z` and `face_z` (solver.jl:183-190)")
         gray = isinstance(radiation_method, GrayRadiation)
         # constructor-time errors of solver.jl:159-181
         if n_gauss_angles != 1:
@@ -107,24 +115,11 @@ class RRTMGPSolver:
         self.clear_net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F") if diag else None
         self._seed = 0
 
-    # ---- prepare_atmosphere!, update_fluxes.jl:252-281 (NoInterpolation) ----------------------
+    # ---- prepare_atmosphere!, update_fluxes.jl:252-281: one device launch -------------------------
     def prepare_atmosphere(self):
-        as_ = self.as_
-        if isinstance(as_, GrayAtmosphericState):
-            return  # gray: p_min clip only applies with lookup tables (get_p_min -> 0 for gray)
-        lw = self.lookups.lookup_lw
-        p_min, t_min, t_max = lw.p_ref_min, lw.t_ref_min, lw.t_ref_max
-        ft = as_.dtype.type
-        # clip!, grid_adaptation.jl:232-258
-        h2o = as_.vmr.vmr_h2o if isinstance(as_.vmr, VmrGM) else as_.vmr.vmr[lw.idx_h2o - 1]
-        np.maximum(h2o, ft(0), out=h2o)
-        np.maximum(as_.layerdata[1], ft(p_min), out=as_.layerdata[1])
-        np.maximum(as_.p_lev, ft(p_min), out=as_.p_lev)
-        np.clip(as_.layerdata[2], ft(t_min), ft(t_max), out=as_.layerdata[2])
-        np.clip(as_.t_lev, ft(t_min), ft(t_max), out=as_.t_lev)
-        # update_concentrations! -> compute_col_gas!(device, ...), grid_adaptation.jl:278-292
-        col_dry = rte.compute_col_gas(self.lws.ws, as_.p_lev, self.params, np.asfortranarray(h2o), as_.lat)
-        as_.layerdata[0] = col_dry
+        grid_adaptation.prepare_atmosphere(self.lws.ws, self.as_, self.params, self.lookups.lookup_lw,
+                                           self.interpolation, self.bottom_extrapolation,
+                                           self.isothermal_boundary_layer, self.center_z, self.face_z)
 
     # ---- update_lw_fluxes!, update_fluxes.jl:12-65 ------------------------------------------------
     def update_lw_fluxes(self):
