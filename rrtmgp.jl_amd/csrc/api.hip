@@ -50,10 +50,14 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
 
 // Number of workgroups for a one-workgroup-per-column kernel: every column gets its
 // own group up to a few resident generations per CU, then groups stride over columns.
-int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes) {
+// Persistent grid of the column kernels: exactly the workgroups that are resident at once
+// (registers AND LDS decide, so ask the runtime), each striding over columns.  A larger grid
+// would run in waves of workgroups and leave the chip half empty during the last one.
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel) {
     if (lds_bytes > 160 * 1024) return set_error(RRTMGP_EUNSUPPORTED, "column does not fit the 160 KB LDS");
-    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds_bytes, 1));
-    per_cu = std::min(per_cu, 2048 / threads);
+    RR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 0;
+    RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes));
     per_cu = std::max(per_cu, 1);
     const int cap = ws->n_cu * per_cu;
     return std::max(1, std::min(ncol, cap));

@@ -282,7 +282,7 @@ static void angular_discretization(int n, double *Ds, double *wts) {
     for (int i = 0; i < n; i++) { Ds[i] = 1.0 / mu[n - 1][i]; wts[i] = w[n - 1][i]; }
 }
 
-int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel);
 
 template <typename FT>
 int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
@@ -315,14 +315,13 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
     ColShared<FT> dummy;
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
-    const int grid = column_grid(ws, as.ncol, threads, lds);
+    auto kern = !twostream ? lw_solve_kernel<FT, false, false>
+                : fl.band_up ? lw_solve_kernel<FT, true, true> : lw_solve_kernel<FT, true, false>;
+    const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
-    auto kern = !twostream ? lw_solve_kernel<FT, false, false>
-                : fl.band_up ? lw_solve_kernel<FT, true, true> : lw_solve_kernel<FT, true, false>;
-    RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
     RR_HIP(hipGetLastError());

@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
     }
 }
 
-int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes);
+int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel);
 
 template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
@@ -271,14 +271,13 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     a.dims = d;
     ColShared<FT> dummy;
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
-    const int grid = column_grid(ws, as.ncol, threads, lds);
+    auto kern = !twostream ? sw_solve_kernel<FT, false, false>
+                : fl.band_up ? sw_solve_kernel<FT, true, true> : sw_solve_kernel<FT, true, false>;
+    const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
-    auto kern = !twostream ? sw_solve_kernel<FT, false, false>
-                : fl.band_up ? sw_solve_kernel<FT, true, true> : sw_solve_kernel<FT, true, false>;
-    RR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
     RR_HIP(hipGetLastError());
