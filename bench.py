@@ -59,6 +59,9 @@ def main():
                          "quoted in DESIGN.md, never the headline value")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1: LW and SW kernels on torch's current stream; 2: each on its own stream (concurrent)")
+    ap.add_argument("--clear-sky-diag", choices=["off", "one-pass", "two-solves"], default="off",
+                    help="also produce clear-sky fluxes (AllSkyRadiationWithClearSkyDiagnostics): in the same launch, "
+                         "or as the reference does with a second, cloudless solve.  Not the default workload.")
     args = ap.parse_args()
 
     import torch
@@ -100,9 +103,26 @@ def main():
     d_lw, d_lw_cld, d_lw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (lw, cl, al))
     d_sw, d_sw_cld, d_sw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (sw, cs, asw))
 
+    clr_lw = clr_sw = None
+    if args.clear_sky_diag != "off":
+        from rrtmgp_jl_amd.states import Flux
+        fdev = None if args.host else dev
+        clr_lw = Flux.allocate(ncol, nlay + 1, ft, sw=False, device=fdev)
+        clr_sw = Flux.allocate(ncol, nlay + 1, ft, sw=True, device=fdev)
+        if args.clear_sky_diag == "two-solves":
+            slv_lw_c = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=fdev, workspace=slv_lw.ws)
+            slv_sw_c = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=fdev, workspace=slv_sw.ws)
+            slv_lw_c.flux, slv_sw_c.flux = clr_lw, clr_sw
+
     def step():
-        rte.solve_lw(slv_lw, as_d, d_lw, d_lw_cld, d_lw_aero, seed=2026, col_offset=col_offset)
-        rte.solve_sw(slv_sw, as_d, d_sw, d_sw_cld, d_sw_aero, seed=2026, col_offset=col_offset)
+        if args.clear_sky_diag == "two-solves":
+            rte.solve_lw(slv_lw_c, as_d, d_lw, None, d_lw_aero, seed=2026, col_offset=col_offset)
+            rte.solve_sw(slv_sw_c, as_d, d_sw, None, d_sw_aero, seed=2026, col_offset=col_offset)
+        one = args.clear_sky_diag == "one-pass"
+        rte.solve_lw(slv_lw, as_d, d_lw, d_lw_cld, d_lw_aero, seed=2026, col_offset=col_offset,
+                     clear_flux=clr_lw if one else None)
+        rte.solve_sw(slv_sw, as_d, d_sw, d_sw_cld, d_sw_aero, seed=2026, col_offset=col_offset,
+                     clear_flux=clr_sw if one else None)
 
     def barrier():
         if world > 1:
@@ -168,7 +188,8 @@ def main():
             "config": {"workload": f"all-sky (McICA clouds, cld_frac={args.cld_frac:g}) LW+SW two-stream, "
                                    f"{ncol} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
                                    f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, "
-                                   f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}",
+                                   f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}"
+                                   + ("" if args.clear_sky_diag == "off" else f", + clear-sky diagnostic ({args.clear_sky_diag})"),
                        "ncol_per_gpu": ncol, "nlay": nlay, "ngpt_lw": lw.n_gpt, "ngpt_sw": sw.n_gpt,
                        "parallelism": f"columns sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

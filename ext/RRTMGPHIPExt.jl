@@ -96,6 +96,7 @@ end
 struct FluxOutDesc
     mem::Int32; layout::Int32; flux_up::P; flux_dn::P; flux_net::P; flux_dn_dir::P
     band_flux_up::P; band_flux_dn::P; band_flux_net::P
+    clear_flux_up::P; clear_flux_dn::P; clear_flux_net::P; clear_flux_dn_dir::P
 end
 struct SolveOpts
     n_gauss_angles::Int32; metric_mem::Int32; metric_scaling::P; seed::UInt64; col_offset::Int64
@@ -227,10 +228,14 @@ end
 # update_net_fluxes! (update_fluxes.jl:198-201), so the solve is not asked for it.
 band_ptrs(::Nothing) = (C_NULL, C_NULL, C_NULL)
 band_ptrs(b) = (ptr(b.flux_up), ptr(b.flux_dn), C_NULL)
+# The clear-sky slots stay NULL: the reference's L2 runs two solves (update_fluxes.jl:39-65), which
+# works unchanged; a host that wants the one-pass form passes its clear-sky buffers here.
 flux_desc(f::FluxLW, band = nothing) =
-    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), C_NULL, band_ptrs(band)...)
+    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), C_NULL, band_ptrs(band)...,
+                C_NULL, C_NULL, C_NULL, C_NULL)
 flux_desc(f::FluxSW, band = nothing) =
-    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), ptr(f.flux_dn_dir), band_ptrs(band)...)
+    FluxOutDesc(0, 0, ptr(f.flux_up), ptr(f.flux_dn), ptr(f.flux_net), ptr(f.flux_dn_dir), band_ptrs(band)...,
+                C_NULL, C_NULL, C_NULL, C_NULL)
 
 # McICA: the host seeds Random (update_fluxes.jl:149-156); one draw from it keys the counter-based stream
 opts(n_angles = 1) = SolveOpts(Int32(n_angles), 0, C_NULL, rand(UInt64), 0)

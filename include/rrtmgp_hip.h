@@ -207,6 +207,17 @@ typedef struct rrtmgp_flux_out {
     void *band_flux_up;
     void *band_flux_dn;
     void *band_flux_net;
+    /* AllSkyRadiationWithClearSkyDiagnostics, src/api/update_fluxes.jl:39-65,101-128: the reference
+     * solves twice (clear, then all-sky) and snapshots the first result.  When clear_flux_up is
+     * non-NULL (clear_flux_dn / _net required with it; clear_flux_dn_dir for SW) and a cloud lookup
+     * is passed to a TWO-STREAM solve, the same launch also carries the recurrences without the
+     * cloud increment — gas optics, sources and aerosols are shared — and writes the clear-sky
+     * fluxes here, same layout and metric scaling as flux_up/dn/net(/dn_dir).  Cannot be combined
+     * with band_flux_* in one call. */
+    void *clear_flux_up;
+    void *clear_flux_dn;
+    void *clear_flux_net;
+    void *clear_flux_dn_dir;
 } rrtmgp_flux_out;
 
 /* Per-call options. */

@@ -77,14 +77,15 @@ def _byref_or_none(d):
 
 
 def solve_lw(as_, bcs, lookup_lw, lookup_cld=None, lookup_aero=None, twostream=True, n_gauss_angles=1,
-             metric_scaling=None, seed=0, col_offset=0, layout=_abi.LAYOUT_NLEV_NCOL, band_flux=None) -> Flux:
-    """`band_flux`: a states.FluxBand to fill (two-stream only), or None."""
+             metric_scaling=None, seed=0, col_offset=0, layout=_abi.LAYOUT_NLEV_NCOL, band_flux=None, clear_flux=None) -> Flux:
+    """`band_flux`: a states.FluxBand to fill (two-stream only), or None.  `clear_flux`: a Flux that
+    receives the clear-sky diagnostic (the reference's first solve of the pair), or None."""
     nlay, ncol = as_.dims
     flux = Flux.allocate(ncol, nlay + 1, as_.dtype, sw=False, layout=layout)
     dl = lookup_lw.desc()
     dc = None if lookup_cld is None else lookup_cld.desc()
     da = None if lookup_aero is None else lookup_aero.desc()
-    ds, db, df = as_.desc(lookup_cld is not None, lookup_aero is not None), bcs.desc(), flux.desc(band_flux)
+    ds, db, df = as_.desc(lookup_cld is not None, lookup_aero is not None), bcs.desc(), flux.desc(band_flux, clear_flux)
     o = _opts(n_gauss_angles, metric_scaling, seed, col_offset)
     fn = lib().rrtmgp_oracle_rte_lw_2stream_solve if twostream else lib().rrtmgp_oracle_rte_lw_noscat_solve
     _check(fn(C.byref(dl), _byref_or_none(dc), _byref_or_none(da), C.byref(ds), C.byref(db), C.byref(df), C.byref(o)),
@@ -93,13 +94,13 @@ def solve_lw(as_, bcs, lookup_lw, lookup_cld=None, lookup_aero=None, twostream=T
 
 
 def solve_sw(as_, bcs, lookup_sw, lookup_cld=None, lookup_aero=None, twostream=True, metric_scaling=None, seed=0,
-             col_offset=0, layout=_abi.LAYOUT_NLEV_NCOL, band_flux=None) -> Flux:
+             col_offset=0, layout=_abi.LAYOUT_NLEV_NCOL, band_flux=None, clear_flux=None) -> Flux:
     nlay, ncol = as_.dims
     flux = Flux.allocate(ncol, nlay + 1, as_.dtype, sw=True, layout=layout)
     dl = lookup_sw.desc()
     dc = None if lookup_cld is None else lookup_cld.desc()
     da = None if lookup_aero is None else lookup_aero.desc()
-    ds, db, df = as_.desc(lookup_cld is not None, lookup_aero is not None), bcs.desc(), flux.desc(band_flux)
+    ds, db, df = as_.desc(lookup_cld is not None, lookup_aero is not None), bcs.desc(), flux.desc(band_flux, clear_flux)
     o = _opts(1, metric_scaling, seed, col_offset)
     if twostream:
         rc = lib().rrtmgp_oracle_rte_sw_2stream_solve(C.byref(dl), _byref_or_none(dc), _byref_or_none(da), C.byref(ds),

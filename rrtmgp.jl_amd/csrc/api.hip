@@ -275,7 +275,7 @@ static int select_device(int device) {
 enum Slot {
     S_LAYERDATA = 0, S_TLEV, S_TSFC, S_VMR_H2O, S_VMR_O3, S_VMR, S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F,
     S_CLD_COVER, S_AERO_SIZE, S_AERO_MASS, S_AOD_EXT, S_AOD_SCA, S_BC0, S_BC1, S_BC2, S_BC3, S_FLUX_UP, S_FLUX_DN,
-    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_ZC, S_ZF, S_NSLOTS
+    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_CLR_UP, S_CLR_DN, S_CLR_NET, S_CLR_DIR, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_ZC, S_ZF, S_NSLOTS
 };
 
 struct Stager {
@@ -387,6 +387,16 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
         TRY(st.out(f->mem, S_BAND_UP, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
         TRY(st.out(f->mem, S_BAND_DN, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
         if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
+    }
+    d.clear_up = d.clear_dn = d.clear_net = d.clear_dir = nullptr;
+    if (f->clear_flux_up || f->clear_flux_dn || f->clear_flux_net || f->clear_flux_dn_dir) {
+        RR_CHECK(nbnd > 0, "the clear-sky diagnostic is only available from the two-stream, non-gray solvers");
+        RR_CHECK(f->clear_flux_up && f->clear_flux_dn && f->clear_flux_net && (!sw || f->clear_flux_dn_dir),
+                 "clear-sky diagnostic: clear_flux_up / _dn / _net (and _dn_dir for SW) go together");
+        TRY(st.out(f->mem, S_CLR_UP, f->clear_flux_up, bytes, (void **)&d.clear_up));
+        TRY(st.out(f->mem, S_CLR_DN, f->clear_flux_dn, bytes, (void **)&d.clear_dn));
+        TRY(st.out(f->mem, S_CLR_NET, f->clear_flux_net, bytes, (void **)&d.clear_net));
+        if (sw) TRY(st.out(f->mem, S_CLR_DIR, f->clear_flux_dn_dir, bytes, (void **)&d.clear_dir));
     }
     d.metric = nullptr;
     if (opts && opts->metric_scaling)

@@ -83,6 +83,7 @@ struct DevFlux {
     int layout;
     const FT *metric;  // (nlev, ncol) or nullptr
     FT *band_up, *band_dn, *band_net;  // optional FluxBand (nlev, ncol, nbnd); band_net may be null on its own
+    FT *clear_up, *clear_dn, *clear_net, *clear_dir;  // optional clear-sky diagnostic (same layout as up/dn/net/dir)
 };
 
 // ---- host-side handles ------------------------------------------------------------

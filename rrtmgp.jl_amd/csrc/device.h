@@ -179,6 +179,7 @@ struct ColDims {
     int lw, twostream, has_cld, has_aero, n_acc /* accumulated flux components per level */;
     int max_int; /* largest minor-interval count of either region */
     int nseg;    /* flux accumulator segments per block: nwaves, or 4 per wave with per-band fluxes */
+    int diag;    /* clear-sky fluxes are carried next to the all-sky ones (n_acc doubles) */
 };
 
 // 4 values read with one ds_read_b128 (Float32) / two (Float64)
@@ -771,14 +772,15 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
     return k < 64 ? ((m0 >> k) & 1ULL) : ((m1 >> (k - 64)) & 1ULL);
 }
 
-// ---- sweep scratch: 3 values per (level, lane), lane-contiguous ----------------------------
-template <typename FT>
+// ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
+// recurrences are carried next to the all-sky ones) ----------------------------------------
+template <typename FT, int NV = 3>
 struct Sweep {
     char *base;     // this workgroup's slab (wave-uniform)
     unsigned lane;  // threadIdx.x * sizeof(FT)
     unsigned row;   // blockDim.x * sizeof(FT)
     __device__ __forceinline__ FT &at(int lev, int a) const {
-        return *reinterpret_cast<FT *>(base + ((unsigned)(lev * 3 + a) * row + lane));
+        return *reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
     }
 };
 
@@ -789,11 +791,14 @@ template <typename FT>
 __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT> &sh, const ColDims &d, int col, int ncol,
                                     bool zero, const DevGas<FT> &lk) {
     const int nlev = d.nlev;
-    for (int lev = threadIdx.x; lev < nlev; lev += blockDim.x) {
+    // accumulator components per level: all-sky (up, dn[, dir]) and, with the clear-sky diagnostic, the same again
+    const int nset = d.diag ? 2 : 1, ncomp = d.n_acc / nset;
+    for (int i = threadIdx.x; i < nlev * nset; i += blockDim.x) {
+        const int set = i / nlev, lev = i - set * nlev;
         FT c[3] = {FT(0), FT(0), FT(0)};
         if (!zero) {
             for (int w = 0; w < d.nseg; w++)
-                for (int a = 0; a < d.n_acc; a++) c[a] += sh.acc[((size_t)w * nlev + lev) * d.n_acc + a];
+                for (int a = 0; a < ncomp; a++) c[a] += sh.acc[((size_t)w * nlev + lev) * d.n_acc + set * ncomp + a];
         }
         FT up = c[0], dn = c[1], dir = c[2];
         FT net = up - dn;
@@ -803,8 +808,13 @@ __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT> &
         }
         const size_t o = fl.layout == RRTMGP_LAYOUT_NCOL_NLEV ? (size_t)col + (size_t)ncol * lev
                                                                : (size_t)lev + (size_t)nlev * col;
-        fl.up[o] = up; fl.dn[o] = dn; fl.net[o] = net;
-        if (d.n_acc == 3 && fl.dir) fl.dir[o] = dir;
+        if (set == 0) {
+            fl.up[o] = up; fl.dn[o] = dn; fl.net[o] = net;
+            if (ncomp == 3 && fl.dir) fl.dir[o] = dir;
+        } else {
+            fl.clear_up[o] = up; fl.clear_dn[o] = dn; fl.clear_net[o] = net;
+            if (ncomp == 3 && fl.clear_dir) fl.clear_dir[o] = dir;
+        }
     }
     // FluxBand (Fluxes.jl:170-215): band b owns the rows [bnd_lo/16, (bnd_lo + bnd_ng)/16); scaled like
     // the broadband fluxes (Fluxes.jl:448-454), net from the scaled values (update_fluxes.jl:198-201)

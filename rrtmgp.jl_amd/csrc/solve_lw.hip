@@ -62,12 +62,10 @@ struct LwArgs {
     int64_t col_offset;
 };
 
-// optics of one layer for this lane: gas + cloud + aerosol increments (TwoStream) or absorption only (OneScalar)
+// cloud + aerosol increments of one layer for this lane (TwoStream), or their absorption only (OneScalar)
 template <typename FT, bool TWOSTREAM>
-__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
-                                                int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
-    const int nb = a.dims.nbnd;
-    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
+__device__ __forceinline__ void lw_layer_increments(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
+                                                    int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g) {
     g = FT(0);
     const int r = kk * NBMAX + lb.ibnd;
     if (a.dims.has_cld && mask_bit(m0, m1, k)) {
@@ -82,10 +80,21 @@ __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColSh
     }
 }
 
+// optics of one layer for this lane: gas, then the increments
+template <typename FT, bool TWOSTREAM>
+__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
+                                                int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
+    gas_optics<FT, false>(a.lk, sh, lb, k, kk, a.dims.nbnd, tau, ssa, pfrac);
+    lw_layer_increments<FT, TWOSTREAM>(a, sh, lb, k, kk, m0, m1, tau, ssa, g);
+}
+
 constexpr int DB = 8;  // levels per batch of the top-down sweeps
 
-template <typename FT, bool TWOSTREAM, bool BAND>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
+// DIAG: the clear-sky recurrences (no cloud increment) are carried next to the all-sky ones in
+// the same launch, sharing the gas optics, sources and aerosol record: the one-pass form of
+// AllSkyRadiationWithClearSkyDiagnostics (update_fluxes.jl:39-65), which the reference solves twice.
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG>
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
@@ -95,8 +104,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x), (unsigned)(tid * sizeof(FT)),
-                 (unsigned)(blockDim.x * sizeof(FT))};
+    constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
+    constexpr int NA = DIAG ? 4 : 2;  // accumulated components per level: up, dn (+ clear up, dn)
+    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * blockDim.x), (unsigned)(tid * sizeof(FT)),
+                     (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CH - 1) / CH;
 
@@ -112,7 +123,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
         }
         const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
         const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)ncol * g] : FT(0);
-        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * d.n_acc;
+        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
 
@@ -124,18 +135,30 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);   // optics of layer k-1
             FT lev_src_bot = FT(0), inc_prev = FT(0);         // lev_source[k-1], B(t_lev[k]) * pfrac[k-1]
             FT albedo = FT(1) - emis, src = FT(0);
+            // clear-sky twin (DIAG): optics of layer k-1 without the cloud increment, and whether they differ
+            FT tau_pc = FT(0), ssa_pc = FT(0), g_pc = FT(0), albedo_c = FT(1) - emis, src_c = FT(0);
+            bool cld_p = false;
+            // one adding step for one of the two streams: voff / aoff = its slots in the sweep record / accumulators
+            auto adding = [&](FT &alb, FT &sr, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff) {
+                const FT denom = m_rcp(FT(1) - Rdif * alb);  // Eq 10
+                sw.at(kl, voff) = Tdif * denom;                        // A
+                sw.at(kl, voff + 1) = (Rdif * sr + src_dn) * denom;    // B
+                sw.at(kl, voff + 2) = alb;
+                const FT ss = seg_sum<BAND>(sr * amask);
+                if (writer) acc[kl * NA + aoff] = ss;
+                const FT alb_n = Rdif + Tdif * Tdif * alb * denom;  // Eq 9
+                sr = src_up + Tdif * denom * (sr + alb * src_dn);   // Eq 11
+                alb = alb_n;
+            };
             auto add_layer = [&](int kl, FT lev_src_top) {   // layer kl between levels kl and kl+1
                 FT Rdif, Tdif, src_up, src_dn;
                 lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
-                const FT denom = m_rcp(FT(1) - Rdif * albedo);  // Eq 10
-                sw.at(kl, 0) = Tdif * denom;                         // A
-                sw.at(kl, 1) = (Rdif * src + src_dn) * denom;        // B
-                sw.at(kl, 2) = albedo;
-                const FT ss = seg_sum<BAND>(src * amask);
-                if (writer) acc[kl * 2] = ss;
-                const FT albedo_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
-                src = src_up + Tdif * denom * (src + albedo * src_dn);    // Eq 11
-                albedo = albedo_n;
+                adding(albedo, src, Rdif, Tdif, src_up, src_dn, kl, 0, 0);
+                if (DIAG) {
+                    // same coefficients unless this lane's McICA sample put a cloud in the layer
+                    if (cld_p) lw_2stream_coeffs(tau_pc, ssa_pc, g_pc, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
+                    adding(albedo_c, src_c, Rdif, Tdif, src_up, src_dn, kl, 3, 2);
+                }
             };
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
@@ -145,7 +168,18 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    FT tau_c = FT(0), ssa_c = FT(0), g_c = FT(0);
+                    bool cld_k = false;
+                    if (DIAG) {
+                        gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
+                        tau_c = tau; ssa_c = ssa;
+                        cld_k = d.has_cld && mask_bit(m0, m1, k);
+                        lw_layer_increments<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg);
+                        if (cld_k) lw_layer_increments<FT, true>(a, sh, lb, k, kk, 0, 0, tau_c, ssa_c, g_c);
+                        else { tau_c = tau; ssa_c = ssa; g_c = gg; }
+                    } else {
+                        lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    }
                     const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
                     FT lev_src_k;
@@ -153,6 +187,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                         const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
                         sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
                         src = Num<FT>::pi() * emis * sfc_source;
+                        src_c = src;
                         lev_src_k = lev_src_dec;
                     } else {
                         lev_src_k = m_sqrt_pos(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
@@ -161,30 +196,42 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                     lev_src_bot = lev_src_k;
                     inc_prev = lev_src_inc;
                     tau_p = tau; ssa_p = ssa; g_p = gg;
+                    if (DIAG) { tau_pc = tau_c; ssa_pc = ssa_c; g_pc = g_c; cld_p = cld_k; }
                 }
             }
             add_layer(nlay - 1, inc_prev);  // lev_source[nlev] = lev_src_inc of the last layer
             // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
-            FT F = inc;
+            FT F = inc, Fc = inc;
             {
                 const FT su = seg_sum<BAND>((F * albedo + src) * amask), sd = seg_sum<BAND>(F * amask);
-                if (writer) { acc[nlay * 2] = su; acc[nlay * 2 + 1] = sd; }
+                if (writer) { acc[nlay * NA] = su; acc[nlay * NA + 1] = sd; }
+                if (DIAG) {
+                    const FT suc = seg_sum<BAND>((Fc * albedo_c + src_c) * amask);
+                    if (writer) { acc[nlay * NA + 2] = suc; acc[nlay * NA + 3] = sd; }
+                }
             }
-            for (int kh = nlay - 1; kh >= 0; kh -= DB) {
-                // DB levels per batch: all scratch loads are issued before the dependent FMA chain
-                FT A[DB], B[DB], AL[DB];
+            constexpr int DBT = DIAG ? 4 : DB;  // the twin doubles the batch registers
+            for (int kh = nlay - 1; kh >= 0; kh -= DBT) {
+                // DBT levels per batch: all scratch loads are issued before the dependent FMA chain
+                FT A[DBT], B[DBT], AL[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], ALc[DIAG ? DBT : 1];
 #pragma unroll
-                for (int j = 0; j < DB; j++) {
+                for (int j = 0; j < DBT; j++) {
                     const int k = kh - j >= 0 ? kh - j : 0;
                     A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2);
+                    if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); ALc[j] = sw.at(k, 5); }
                 }
 #pragma unroll
-                for (int j = 0; j < DB; j++) {
+                for (int j = 0; j < DBT; j++) {
                     if (kh - j >= 0) {
                         const int k = kh - j;
                         F = A[j] * F + B[j];
                         const FT su = seg_sum<BAND>(F * AL[j] * amask), sd = seg_sum<BAND>(F * amask);
-                        if (writer) { acc[k * 2] += su; acc[k * 2 + 1] = sd; }
+                        if (writer) { acc[k * NA] += su; acc[k * NA + 1] = sd; }
+                        if (DIAG) {
+                            Fc = Ac[j] * Fc + Bc[j];
+                            const FT suc = seg_sum<BAND>(Fc * ALc[j] * amask), sdc = seg_sum<BAND>(Fc * amask);
+                            if (writer) { acc[k * NA + 2] += suc; acc[k * NA + 3] = sdc; }
+                        }
                     }
                 }
             }
@@ -306,7 +353,8 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
     d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
-    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 2; d.max_int = max_int;
+    const bool diag = fl.clear_up != nullptr;
+    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 4 : 2; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     a.n_angles = twostream ? 1 : n_angles;
@@ -315,11 +363,16 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
     ColShared<FT> dummy;
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
-    auto kern = !twostream ? lw_solve_kernel<FT, false, false>
-                : fl.band_up ? lw_solve_kernel<FT, true, true> : lw_solve_kernel<FT, true, false>;
+    if (diag) {
+        RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
+        RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
+    }
+    auto kern = !twostream ? lw_solve_kernel<FT, false, false, false>
+                : diag     ? lw_solve_kernel<FT, true, false, true>
+                : fl.band_up ? lw_solve_kernel<FT, true, true, false> : lw_solve_kernel<FT, true, false, false>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));

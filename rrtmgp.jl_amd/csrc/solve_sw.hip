@@ -76,8 +76,9 @@ struct SwArgs {
 
 constexpr int DB = 8;  // levels per batch of the light sweeps
 
-template <typename FT, bool TWOSTREAM, bool BAND>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
+// DIAG: clear-sky recurrences carried next to the all-sky ones (see lw_solve_kernel)
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG>
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
     carve_shared(sh, smem, a.dims);
@@ -87,8 +88,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
     const bool active = tid < a.lk.n_gpt;
     const int g = active ? tid : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
-    Sweep<FT> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * 3 * blockDim.x), (unsigned)(tid * sizeof(FT)),
-                 (unsigned)(blockDim.x * sizeof(FT))};
+    constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
+    constexpr int NA = DIAG ? 6 : 3;  // accumulated components per level: up, dn, dir (+ the clear-sky three)
+    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * blockDim.x), (unsigned)(tid * sizeof(FT)),
+                     (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CH - 1) / CH;
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             continue;
         }
         prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
-        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * d.n_acc;
+        FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
 
         if (!TWOSTREAM) {
@@ -154,12 +157,33 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
             // 3 stored values per level; delta only enters D additively, so it is summed on the fly. ----
             const FT dir_top = a.toa_flux[col] * solar_frac * mu0;
             const FT inv_mu0 = FT(1) / m_max(mu0, mu0_min<FT>());
-            FT tau_cum = FT(0), dir_above = dir_top;
-            FT beta = FT(0), delta = FT(0);
+            // one stream of the top-down adding: all-sky, and (DIAG) its clear-sky twin
+            struct Stream { FT tau_cum, dir_above, beta, delta; };
+            Stream S{FT(0), dir_top, FT(0), FT(0)}, C{FT(0), dir_top, FT(0), FT(0)};
             {
                 const FT s = seg_sum<BAND>(dir_top * amask);
-                if (writer) { acc[nlay * 3 + 2] = s; acc[nlay * 3 + 1] = FT(0); }
+                if (writer) {
+                    acc[nlay * NA + 2] = s; acc[nlay * NA + 1] = FT(0);
+                    if (DIAG) { acc[nlay * NA + 5] = s; acc[nlay * NA + 4] = FT(0); }
+                }
             }
+            auto layer = [&](Stream &t, FT tau, FT ssa, FT gg, int k, int voff, int aoff, FT &Rdir, FT &Tdir, FT &Rdif,
+                             FT &Tdif, bool recompute) {
+                t.tau_cum += tau;
+                const FT dir_k = dir_top * m_exp(-t.tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
+                if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
+                const FT s_up = Rdir * t.dir_above, s_dn = Tdir * t.dir_above;
+                const FT den = m_rcp(FT(1) - t.beta * Rdif);
+                sw.at(k, voff) = Tdif * den;                       // U_{k+1} = A U_k + B
+                sw.at(k, voff + 1) = (Rdif * t.delta + s_up) * den;
+                sw.at(k, voff + 2) = t.beta;                       // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
+                const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
+                t.delta = s_dn + Tdif * den * (t.delta + t.beta * s_up);
+                t.beta = beta_n;
+                const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(t.delta * amask);
+                if (writer) { acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel; }
+                t.dir_above = dir_k;
+            };
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
@@ -169,48 +193,58 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) sw_
                     const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
                     FT tau, ssa, pf, gg = FT(0);
                     gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
-                    if (d.has_cld && mask_bit(m0, m1, k)) { const V4<FT> cr = sh.ch->cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
-                    if (d.has_aero && sh.lay[k].aero_mask) { const V4<FT> cr = sh.ch->aer[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
-                    tau_cum += tau;
-                    const FT dir_k = dir_top * m_exp(-tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
+                    FT tau_c = tau, ssa_c = ssa, g_c = FT(0);
+                    const bool cld_k = d.has_cld && mask_bit(m0, m1, k);
+                    if (cld_k) { const V4<FT> cr = sh.ch->cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
+                    if (d.has_aero && sh.lay[k].aero_mask) {
+                        const V4<FT> cr = sh.ch->aer[r];
+                        increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z);
+                        if (DIAG && cld_k) increment_2stream(tau_c, ssa_c, g_c, cr.x, cr.y, cr.z);
+                    }
                     FT Rdir, Tdir, Rdif, Tdif;
-                    sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
-                    const FT s_up = Rdir * dir_above, s_dn = Tdir * dir_above;
-                    const FT den = m_rcp(FT(1) - beta * Rdif);
-                    sw.at(k, 0) = Tdif * den;                       // U_{k+1} = A U_k + B
-                    sw.at(k, 1) = (Rdif * delta + s_up) * den;
-                    sw.at(k, 2) = beta;                             // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
-                    const FT beta_n = Rdif + Tdif * Tdif * beta * den;
-                    delta = s_dn + Tdif * den * (delta + beta * s_up);
-                    beta = beta_n;
-                    const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(delta * amask);
-                    if (writer) { acc[k * 3 + 2] = sdir; acc[k * 3 + 1] = sdel; }
-                    dir_above = dir_k;
+                    layer(S, tau, ssa, gg, k, 0, 0, Rdir, Tdir, Rdif, Tdif, true);
+                    if (DIAG) {
+                        // without a cloud in this lane's sample the clear layer IS the all-sky layer: reuse its coefficients
+                        if (!cld_k) { tau_c = tau; ssa_c = ssa; g_c = gg; }
+                        layer(C, tau_c, ssa_c, g_c, k, 3, 3, Rdir, Tdir, Rdif, Tdif, cld_k);
+                    }
                 }
             }
             // ---- surface: U_1 = alb_dif D_1 + dir_sfc alb_dir, D_1 = beta_1 U_1 + delta_1 ----
             const FT alb = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
-            const FT sfc_src = dir_above * a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
-            FT U = m_div(alb * delta + sfc_src, FT(1) - alb * beta);
+            const FT alb_d = a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
+            FT U = m_div(alb * S.delta + S.dir_above * alb_d, FT(1) - alb * S.beta);
+            FT Uc = DIAG ? m_div(alb * C.delta + C.dir_above * alb_d, FT(1) - alb * C.beta) : FT(0);
             {
-                const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(beta * U * amask);
+                const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(S.beta * U * amask);
                 if (writer) { acc[0] = su; acc[1] = (acc[1] + sb) + acc[2]; }
+                if (DIAG) {
+                    const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(C.beta * Uc * amask);
+                    if (writer) { acc[3] = suc; acc[4] = (acc[4] + sbc) + acc[5]; }
+                }
             }
             // ---- sweep 2, bottom-up: fluxes ----
-            for (int kl = 0; kl < nlay; kl += DB) {
-                FT A[DB], B[DB], BE[DB];
+            constexpr int DBT = DIAG ? 4 : DB;
+            for (int kl = 0; kl < nlay; kl += DBT) {
+                FT A[DBT], B[DBT], BE[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], BEc[DIAG ? DBT : 1];
 #pragma unroll
-                for (int j = 0; j < DB; j++) {
+                for (int j = 0; j < DBT; j++) {
                     const int k = kl + j < nlay ? kl + j : nlay - 1;
                     A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); BE[j] = sw.at(k, 2);
+                    if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); BEc[j] = sw.at(k, 5); }
                 }
 #pragma unroll
-                for (int j = 0; j < DB; j++) {
+                for (int j = 0; j < DBT; j++) {
                     if (kl + j < nlay) {
                         const int lev = kl + j + 1;
                         U = A[j] * U + B[j];
                         const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
-                        if (writer) { acc[lev * 3] = su; acc[lev * 3 + 1] = (acc[lev * 3 + 1] + sb) + acc[lev * 3 + 2]; }
+                        if (writer) { acc[lev * NA] = su; acc[lev * NA + 1] = (acc[lev * NA + 1] + sb) + acc[lev * NA + 2]; }
+                        if (DIAG) {
+                            Uc = Ac[j] * Uc + Bc[j];
+                            const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(BEc[j] * Uc * amask);
+                            if (writer) { acc[lev * NA + 3] = suc; acc[lev * NA + 4] = (acc[lev * NA + 4] + sbc) + acc[lev * NA + 5]; }
+                        }
                     }
                 }
             }
@@ -266,16 +300,22 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
         if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
     }
     d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
-    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = 3; d.max_int = max_int;
+    const bool diag = fl.clear_up != nullptr;
+    d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 6 : 3; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     ColShared<FT> dummy;
     const size_t lds = carve_shared(dummy, (char *)nullptr, d);
-    auto kern = !twostream ? sw_solve_kernel<FT, false, false>
-                : fl.band_up ? sw_solve_kernel<FT, true, true> : sw_solve_kernel<FT, true, false>;
+    if (diag) {
+        RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
+        RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
+    }
+    auto kern = !twostream ? sw_solve_kernel<FT, false, false, false>
+                : diag     ? sw_solve_kernel<FT, true, false, true>
+                : fl.band_up ? sw_solve_kernel<FT, true, true, false> : sw_solve_kernel<FT, true, false, false>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * 3 * threads * sizeof(FT));
+    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT));
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));

@@ -151,11 +151,12 @@ def _null(h):
 
 
 def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=None, metric_scaling=None,
-             seed: int = 0, col_offset: int = 0) -> Flux:
-    """solve_lw! (RTESolver.jl:33,54,77,117).  Gray when `as_` is a GrayAtmosphericState."""
+             seed: int = 0, col_offset: int = 0, clear_flux: Optional[Flux] = None) -> Flux:
+    """solve_lw! (RTESolver.jl:33,54,77,117).  Gray when `as_` is a GrayAtmosphericState.
+    `clear_flux`: also produce the clear-sky fluxes in the same launch (two-stream + cloud lookup)."""
     L = _lib.lib()
     o = _opts(slv.n_gauss_angles, metric_scaling, seed, col_offset)
-    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux)
+    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux, clear_flux)
     if isinstance(as_, GrayAtmosphericState):
         if slv.n_gauss_angles != 1:
             raise ValueError("gray radiation is solved with a single quadrature angle")
@@ -172,11 +173,11 @@ def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=
 
 
 def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=None, metric_scaling=None,
-             seed: int = 0, col_offset: int = 0) -> Flux:
+             seed: int = 0, col_offset: int = 0, clear_flux: Optional[Flux] = None) -> Flux:
     """solve_sw! (RTESolver.jl:151,167,188,222)."""
     L = _lib.lib()
     o = _opts(1, metric_scaling, seed, col_offset)
-    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux)
+    db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux, clear_flux)
     if isinstance(as_, GrayAtmosphericState):
         dg = as_.desc()
         fn = L.rrtmgp_hip_rte_sw_2stream_solve_gray if slv.twostream else L.rrtmgp_hip_rte_sw_noscat_solve_gray

@@ -132,6 +132,10 @@ class RRTMGPSolver:
             rte.solve_lw(self.lws, self.as_, lk.lookup_lw, None, aero, ms, seed=self._seed)
         elif isinstance(m, AllSkyRadiation):
             rte.solve_lw(self.lws, self.as_, lk.lookup_lw, lk.lookup_lw_cld, aero, ms, seed=self._seed)
+        elif self.lws.twostream and self.lws.band_flux is None:
+            # one launch carries both recurrences (the reference solves twice, update_fluxes.jl:39-65)
+            rte.solve_lw(self.lws, self.as_, lk.lookup_lw, lk.lookup_lw_cld, aero, ms, seed=self._seed,
+                         clear_flux=self.clear_flux_lw)
         else:
             rte.solve_lw(self.lws, self.as_, lk.lookup_lw, None, aero, ms, seed=self._seed)
             for n in ("flux_up", "flux_dn", "flux_net"):
@@ -149,6 +153,9 @@ class RRTMGPSolver:
             rte.solve_sw(self.sws, self.as_, lk.lookup_sw, None, aero, ms, seed=self._seed)
         elif isinstance(m, AllSkyRadiation):
             rte.solve_sw(self.sws, self.as_, lk.lookup_sw, lk.lookup_sw_cld, aero, ms, seed=self._seed)
+        elif self.sws.twostream and self.sws.band_flux is None:
+            rte.solve_sw(self.sws, self.as_, lk.lookup_sw, lk.lookup_sw_cld, aero, ms, seed=self._seed,
+                         clear_flux=self.clear_flux_sw)
         else:
             rte.solve_sw(self.sws, self.as_, lk.lookup_sw, None, aero, ms, seed=self._seed)
             for n in ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"):

@@ -222,10 +222,19 @@ class Flux(_Container):
             arrs = [torch.full(tuple(reversed(shape)), float("nan"), dtype=tdt, device=device) for _ in range(n)]
         return Flux(arrs[0], arrs[1], arrs[2], arrs[3] if sw else None, layout)
 
-    def desc(self, band: "FluxBand" = None) -> _abi.FluxOut:
+    def desc(self, band: "FluxBand" = None, clear: "Flux" = None) -> _abi.FluxOut:
+        """`clear`: a second Flux of the same shape that receives the one-pass clear-sky diagnostic."""
         d = _abi.FluxOut()
         mems = set()
         self._set_ptrs(d, ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"), mems)
+        if clear is not None:
+            if clear.layout != self.layout:
+                raise ValueError("clear-sky flux buffers must use the layout of the all-sky ones")
+            for n in ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"):
+                p, m = array_ptr(getattr(clear, n))
+                setattr(d, "clear_" + n, p)
+                if m is not None:
+                    mems.add(m)
         if band is not None:
             for n in ("flux_up", "flux_dn", "flux_net"):
                 p, m = array_ptr(getattr(band, n))
