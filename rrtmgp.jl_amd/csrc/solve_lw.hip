@@ -21,6 +21,22 @@ template <typename FT>
 __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_src_bot, FT lev_src_top, FT &Rdif,
                                                   FT &Tdif, FT &src_up, FT &src_dn) {
     const FT lw_diff_sec = FT(1.66);
+    if (__all(ssa == FT(0))) {
+        // Every lane of the wavefront is a purely absorbing layer (gas only: 3 of 4 cells of an all-sky
+        // column).  The expressions below are the general ones with ssa = 0 substituted: gamma1 = D,
+        // gamma2 = 0, k = D, RT_term = 1/(2D), hence Rdif = 0, Tdif = e^{-D tau}, emis_fac = 1 - Tdif and
+        // dBz = dB (1 - Tdif) / (D tau).  No sqrt, one reciprocal instead of three.
+        FT e1, om1;
+        exp_pair(tau * lw_diff_sec, e1, om1);
+        Rdif = FT(0);
+        Tdif = e1;
+        const FT dB = lev_src_bot - lev_src_top;
+        const FT dBz = m_div(dB * om1, lw_diff_sec * tau);
+        const bool pos = tau > FT(0);
+        src_up = pos ? Num<FT>::pi() * (lev_src_top * om1 - e1 * dB + dBz) : FT(0);
+        src_dn = pos ? Num<FT>::pi() * (lev_src_bot * om1 + e1 * dB - dBz) : FT(0);
+        return;
+    }
     const FT gamma1 = lw_diff_sec * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
     const FT gamma2 = lw_diff_sec * FT(0.5) * ssa * (FT(1) - g);
     const FT k = m_sqrt_pos(m_max(lw_diff_sec * (FT(1) - ssa) * (gamma1 + gamma2), k_min<FT>()));
