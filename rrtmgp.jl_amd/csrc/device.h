@@ -217,8 +217,8 @@ struct alignas(32) ChunkFixed {
     V4<FT> cld[CH * NBMAX];  // cloud (tau, ssa, g, -) or (absorption tau, -, -, -)
     V4<FT> aer[CH * NBMAX];
     FT Blev[(CH + 1) * NBMAX];
-    FT Blay[CH * NBMAX];
     int je[CH * NBMAX];      // je1 | je2 << 8
+    FT Blay[CH * NBMAX];     // layer Planck sources: no-scattering LW only; last, so the other solvers do not allocate it
 };
 
 template <typename FT>
@@ -244,6 +244,7 @@ template <typename FT>
 __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
     char *p = base;
     s.ch = carve<ChunkFixed<FT>>(p, 1);
+    if (!(d.lw && !d.twostream)) p -= sizeof(FT) * CH * NBMAX;  // Blay (a multiple of 32 bytes)
     s.lay = carve<LayerRec<FT>>(p, d.nlay);
     s.lev = carve<LevelRec<FT>>(p, d.nlev);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
@@ -534,7 +535,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         }
         sh.ch->je[t] = je[0] | (je[1] << 8);
         sh.ch->eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
-        if (d.lw) {
+        if (d.lw && !d.twostream) {  // layer sources: no-scattering solver only (Blay is not allocated otherwise)
             const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lay[k].pl_lay_loc;
             sh.ch->Blay[t] = tp[0] * (FT(1) - sh.lay[k].pl_lay_f) + tp[1] * sh.lay[k].pl_lay_f;
         }
