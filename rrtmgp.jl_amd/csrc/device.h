@@ -701,7 +701,7 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
         // groups of MG intervals: every load of a group is in flight before the first use; slots past
         // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
-        constexpr int MG = 4;
+        constexpr int MG = 3;
         const unsigned cstep = lb.ngb * E;
         for (int i0 = 0; i0 < n; i0 += MG) {
             FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];

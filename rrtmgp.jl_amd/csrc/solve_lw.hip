@@ -104,7 +104,7 @@ __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColSh
     lw_layer_increments<FT, TWOSTREAM>(a, sh, lb, k, kk, m0, m1, tau, ssa, g);
 }
 
-constexpr int DB = 8;  // levels per batch of the top-down sweeps
+constexpr int DB = 16;  // levels per batch of the top-down sweeps
 
 // DIAG: the clear-sky recurrences (no cloud increment) are carried next to the all-sky ones in
 // the same launch, sharing the gas optics, sources and aerosol record: the one-pass form of
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     if (writer) { acc[nlay * NA + 2] = suc; acc[nlay * NA + 3] = sd; }
                 }
             }
-            constexpr int DBT = DIAG ? 4 : DB;  // the twin doubles the batch registers
+            constexpr int DBT = DIAG ? DB / 2 : DB;  // the twin doubles the batch registers
             for (int kh = nlay - 1; kh >= 0; kh -= DBT) {
                 // DBT levels per batch: all scratch loads are issued before the dependent FMA chain
                 FT A[DBT], B[DBT], AL[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], ALc[DIAG ? DBT : 1];

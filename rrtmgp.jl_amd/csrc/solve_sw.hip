@@ -74,7 +74,7 @@ struct SwArgs {
     int64_t col_offset;
 };
 
-constexpr int DB = 8;  // levels per batch of the light sweeps
+constexpr int DB = 16;  // levels per batch of the light sweeps
 
 // DIAG: clear-sky recurrences carried next to the all-sky ones (see lw_solve_kernel)
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG>
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 }
             }
             // ---- sweep 2, bottom-up: fluxes ----
-            constexpr int DBT = DIAG ? 4 : DB;
+            constexpr int DBT = DIAG ? DB / 2 : DB;
             for (int kl = 0; kl < nlay; kl += DBT) {
                 FT A[DBT], B[DBT], BE[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], BEc[DIAG ? DBT : 1];
 #pragma unroll
