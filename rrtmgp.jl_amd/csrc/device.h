@@ -173,6 +173,74 @@ __device__ __forceinline__ FT seg_sum(FT v) {
     return BAND ? row_sum(v) : wave_sum_to_lane63(v);
 }
 
+// ---- 16 wavefront sums at once ----------------------------------------------------------
+// Summing ONE value over the 64 lanes costs 6 dependent DPP adds (plus their hazard nops).  16
+// values are cheaper together: v_permlane32_swap / v_permlane16_swap exchange half-wavefronts and
+// odd/even rows of a register PAIR, so one swap + one add halves two values at a time
+// (16 -> 8 -> 4 registers, each row then holding a different value), and only 4 registers need
+// the 4 in-row DPP steps.  40 instructions instead of 96, and independent chains (no nops).
+// (Inline asm: with ROCm 7.2 the __builtin_amdgcn_permlane{16,32}_swap intrinsics lose their second
+// result for 32-bit values — `v_add v1, v1, v1` after the swap; tools/ubench/wave_sum16_test.hip.
+// The s_nop's: the operands may have been written by the VALU instruction just before and are read
+// by the one just after; without them the sums are wrong — the compiler's hazard recogniser does not
+// see through inline asm.  The swaps of one stage share one pair of nops.)
+// x[i] <-> y[i] across the two half-wavefronts: x[i] = [x_lo, y_lo], y[i] = [x_hi, y_hi]
+__device__ __forceinline__ void lane_swap32x4(unsigned (&x)[4], unsigned (&y)[4]) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                 "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+// odd rows of x[i] <-> even rows of y[i]: x[i] = [x_r0, y_r0, x_r2, y_r2], y[i] = [x_r1, y_r1, x_r3, y_r3]
+__device__ __forceinline__ void lane_swap16x4(unsigned (&x)[4], unsigned (&y)[4]) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                 "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\ts_nop 1"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]));
+}
+template <bool HALVES>
+__device__ __forceinline__ void lane_swap_x4(float (&x)[4], float (&y)[4]) {
+    unsigned ux[4], uy[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ux[i] = __builtin_bit_cast(unsigned, x[i]); uy[i] = __builtin_bit_cast(unsigned, y[i]); }
+    if (HALVES) lane_swap32x4(ux, uy); else lane_swap16x4(ux, uy);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { x[i] = __builtin_bit_cast(float, ux[i]); y[i] = __builtin_bit_cast(float, uy[i]); }
+}
+template <bool HALVES>
+__device__ __forceinline__ void lane_swap_x4(double (&x)[4], double (&y)[4]) {
+    unsigned xl[4], xh[4], yl[4], yh[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long a = __builtin_bit_cast(unsigned long long, x[i]), b = __builtin_bit_cast(unsigned long long, y[i]);
+        xl[i] = (unsigned)a; xh[i] = (unsigned)(a >> 32); yl[i] = (unsigned)b; yh[i] = (unsigned)(b >> 32);
+    }
+    if (HALVES) { lane_swap32x4(xl, yl); lane_swap32x4(xh, yh); } else { lane_swap16x4(xl, yl); lane_swap16x4(xh, yh); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        x[i] = __builtin_bit_cast(double, ((unsigned long long)xh[i] << 32) | xl[i]);
+        y[i] = __builtin_bit_cast(double, ((unsigned long long)yh[i] << 32) | yl[i]);
+    }
+}
+// On return every lane of DPP row r (lanes 16r .. 16r+15) holds in w[i] the wavefront sum of v[i + 4 r].
+template <typename FT>
+__device__ __forceinline__ void wave_sum16(const FT (&v)[16], FT (&w)[4]) {
+    FT a[4], b[4], u[8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {  // pairs (v[i], v[i + 8]), four at a time
+#pragma unroll
+        for (int i = 0; i < 4; i++) { a[i] = v[4 * h + i]; b[i] = v[4 * h + i + 8]; }
+        lane_swap_x4<true>(a, b);
+#pragma unroll
+        for (int i = 0; i < 4; i++) u[4 * h + i] = a[i] + b[i];  // lanes 0-31: v[i] over both halves; 32-63: v[i + 8]
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a[i] = u[i]; b[i] = u[i + 4]; }
+    lane_swap_x4<false>(a, b);
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = a[i] + b[i];  // rows 0..3: v[i], v[i + 4], v[i + 8], v[i + 12] over the four rows
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = row_sum(w[i]);
+}
+
 // ---- dimensions + LDS carve ----------------------------------------------------------
 struct ColDims {
     int nlay, nlev, ngas1 /* rows of the gas table */, nwaves, nbnd;

@@ -236,17 +236,39 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2);
                     if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); ALc[j] = sw.at(k, 5); }
                 }
+                if (!BAND && !DIAG && DBT == 16) {
+                    // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
+                    FT pu[16], pd[16];
 #pragma unroll
-                for (int j = 0; j < DBT; j++) {
-                    if (kh - j >= 0) {
-                        const int k = kh - j;
-                        F = A[j] * F + B[j];
-                        const FT su = seg_sum<BAND>(F * AL[j] * amask), sd = seg_sum<BAND>(F * amask);
-                        if (writer) { acc[k * NA] += su; acc[k * NA + 1] = sd; }
-                        if (DIAG) {
-                            Fc = Ac[j] * Fc + Bc[j];
-                            const FT suc = seg_sum<BAND>(Fc * ALc[j] * amask), sdc = seg_sum<BAND>(Fc * amask);
-                            if (writer) { acc[k * NA + 2] += suc; acc[k * NA + 3] = sdc; }
+                    for (int j = 0; j < 16; j++) {
+                        const bool in = kh - j >= 0;
+                        if (in) F = A[j] * F + B[j];
+                        pu[j] = in ? F * AL[j] * amask : FT(0);
+                        pd[j] = in ? F * amask : FT(0);
+                    }
+                    FT wu[4], wd[4];
+                    wave_sum16(pu, wu);
+                    wave_sum16(pd, wd);
+                    if ((lane & 15) == 15) {  // row r holds batch entries j = i + 4 r
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int k = kh - (i + 4 * (lane >> 4));
+                            if (k >= 0) { acc[k * NA] += wu[i]; acc[k * NA + 1] = wd[i]; }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DBT; j++) {
+                        if (kh - j >= 0) {
+                            const int k = kh - j;
+                            F = A[j] * F + B[j];
+                            const FT su = seg_sum<BAND>(F * AL[j] * amask), sd = seg_sum<BAND>(F * amask);
+                            if (writer) { acc[k * NA] += su; acc[k * NA + 1] = sd; }
+                            if (DIAG) {
+                                Fc = Ac[j] * Fc + Bc[j];
+                                const FT suc = seg_sum<BAND>(Fc * ALc[j] * amask), sdc = seg_sum<BAND>(Fc * amask);
+                                if (writer) { acc[k * NA + 2] += suc; acc[k * NA + 3] = sdc; }
+                            }
                         }
                     }
                 }

@@ -233,17 +233,41 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); BE[j] = sw.at(k, 2);
                     if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); BEc[j] = sw.at(k, 5); }
                 }
+                if (!BAND && !DIAG && DBT == 16) {
+                    FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions
 #pragma unroll
-                for (int j = 0; j < DBT; j++) {
-                    if (kl + j < nlay) {
-                        const int lev = kl + j + 1;
-                        U = A[j] * U + B[j];
-                        const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
-                        if (writer) { acc[lev * NA] = su; acc[lev * NA + 1] = (acc[lev * NA + 1] + sb) + acc[lev * NA + 2]; }
-                        if (DIAG) {
-                            Uc = Ac[j] * Uc + Bc[j];
-                            const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(BEc[j] * Uc * amask);
-                            if (writer) { acc[lev * NA + 3] = suc; acc[lev * NA + 4] = (acc[lev * NA + 4] + sbc) + acc[lev * NA + 5]; }
+                    for (int j = 0; j < 16; j++) {
+                        const bool in = kl + j < nlay;
+                        if (in) U = A[j] * U + B[j];
+                        pu[j] = in ? U * amask : FT(0);
+                        pb[j] = in ? BE[j] * U * amask : FT(0);
+                    }
+                    FT wu[4], wb[4];
+                    wave_sum16(pu, wu);
+                    wave_sum16(pb, wb);
+                    if ((lane & 15) == 15) {  // row r holds batch entries j = i + 4 r
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = i + 4 * (lane >> 4), lev = kl + j + 1;
+                            if (kl + j < nlay) {
+                                acc[lev * NA] = wu[i];
+                                acc[lev * NA + 1] = (acc[lev * NA + 1] + wb[i]) + acc[lev * NA + 2];
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < DBT; j++) {
+                        if (kl + j < nlay) {
+                            const int lev = kl + j + 1;
+                            U = A[j] * U + B[j];
+                            const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
+                            if (writer) { acc[lev * NA] = su; acc[lev * NA + 1] = (acc[lev * NA + 1] + sb) + acc[lev * NA + 2]; }
+                            if (DIAG) {
+                                Uc = Ac[j] * Uc + Bc[j];
+                                const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(BEc[j] * Uc * amask);
+                                if (writer) { acc[lev * NA + 3] = suc; acc[lev * NA + 4] = (acc[lev * NA + 4] + sbc) + acc[lev * NA + 5]; }
+                            }
                         }
                     }
                 }
