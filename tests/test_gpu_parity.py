@@ -10,6 +10,7 @@ Tolerances (W/m^2 unless noted), from the reference's own CI budget:
   * Float32 HIP vs Float32 oracle: LW 1e-3, SW 2e-2 (same budget class; both carry F32 rounding).
 """
 import dataclasses
+import os
 
 import numpy as np
 import pytest
@@ -349,3 +350,20 @@ def test_rrtmgp_solver_gray_and_constructor_errors():
         L2.RRTMGPSolver(L2.GrayRadiation(), params, lb, sb, gs, n_gauss_angles=2)
     with pytest.raises(ValueError):
         L2.RRTMGPSolver(L2.ClearSkyRadiation(), params, lb, sb, gs, op_sw="onescalar", lookups=L2.LookupBundle())
+
+
+def test_wave_sum16_device_unit_test(tmp_path):
+    """The 16-at-a-time g-point reduction (device.h `wave_sum16`, v_permlane{32,16}_swap) on its own:
+    compiled from tools/ubench/wave_sum16_test.hip against the library's headers and run on the GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "wave_sum16_test")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "rrtmgp.jl_amd", "csrc"),
+                    "-I", os.path.join(root, "include"), os.path.join(root, "tools", "ubench", "wave_sum16_test.hip"),
+                    "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
