@@ -150,11 +150,32 @@ def _null(h):
     return None if h is None else h.handle
 
 
+def _check_precision(slv: "_RTE", as_, *lookups):
+    """The C structs carry raw pointers: element type and extents are the caller's contract.  The
+    reference gets the same guarantees from its type parameters (`RTE{FT}`, `AtmosphericState{FT}`)."""
+    want = slv.ws.dtype
+    got = np.dtype(as_.dtype)
+    if got != want:
+        raise TypeError(f"state arrays are {got}, the workspace was created for {want}")
+    for f in ("flux_up",):
+        if np.dtype(array_dtype(getattr(slv.flux, f))) != want:
+            raise TypeError(f"flux buffers are not {want}")
+    for lk in lookups:
+        host = getattr(lk, "host", lk)
+        if host is not None and np.dtype(host.dtype) != want:
+            raise TypeError(f"lookup tables are {np.dtype(host.dtype)}, the workspace was created for {want}")
+    nlay, ncol = as_.dims
+    if nlay != slv.ws.nlay or ncol > slv.ws.ncol:
+        raise ValueError(f"state is (nlay={nlay}, ncol={ncol}); the workspace was created for "
+                         f"(nlay={slv.ws.nlay}, ncol<={slv.ws.ncol})")
+
+
 def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=None, metric_scaling=None,
              seed: int = 0, col_offset: int = 0, clear_flux: Optional[Flux] = None) -> Flux:
     """solve_lw! (RTESolver.jl:33,54,77,117).  Gray when `as_` is a GrayAtmosphericState.
     `clear_flux`: also produce the clear-sky fluxes in the same launch (two-stream + cloud lookup)."""
     L = _lib.lib()
+    _check_precision(slv, as_, lookup_lw, lookup_lw_cld, lookup_lw_aero)
     o = _opts(slv.n_gauss_angles, metric_scaling, seed, col_offset)
     db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux, clear_flux)
     if isinstance(as_, GrayAtmosphericState):
@@ -176,6 +197,7 @@ def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=
              seed: int = 0, col_offset: int = 0, clear_flux: Optional[Flux] = None) -> Flux:
     """solve_sw! (RTESolver.jl:151,167,188,222)."""
     L = _lib.lib()
+    _check_precision(slv, as_, lookup_sw, lookup_sw_cld, lookup_sw_aero)
     o = _opts(1, metric_scaling, seed, col_offset)
     db, df = slv.bcs.desc(), slv.flux.desc(slv.band_flux, clear_flux)
     if isinstance(as_, GrayAtmosphericState):
