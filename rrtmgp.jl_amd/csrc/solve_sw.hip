@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
-            a.as.cld_cover[col] = FT(n) / FT(a.lk.n_gpt);
+            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
         }
         __syncthreads();
     }

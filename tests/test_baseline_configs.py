@@ -1,0 +1,113 @@
+"""The five configurations of BASELINE.json, one test each, through the C ABI on the GPU.
+
+configs[0] gray LW no-scattering, ncol = 1, nlay = 60, Float64 (test/gray_atm.jl plumbing)
+configs[1] RFMIP-shaped clear sky, 100 columns x 60 layers, LW + SW no-scattering, Float64
+configs[2] cloudy two-stream LW + SW with McICA, 128 columns x 64 layers, Float32
+configs[3] all-sky + MERRA aerosols, 4096 columns x 73 layers, two-stream, sharded 1 -> 8 ways
+configs[4] GCM scale, 1 048 576 columns x 64 layers, Float32, column-sharded over 8 GPUs
+           (here: one GPU's 131 072-column shard of that global problem)
+Tolerances: Float64 1e-8 W/m2 against the oracle; Float32 inside the reference's F32 budget
+(test/float32_consistency.jl:53-62: LW 1e-3, SW 3e-2 clear / 1.2e-1 cloudy)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rrtmgp_jl_amd import rte, sharding, synthetic as S
+from rrtmgp_jl_amd.states import GrayOpticalThicknessSchneider2004, LwBCs, RRTMGPParameters
+
+pytestmark = pytest.mark.gpu
+LWN, SWN = ("flux_up", "flux_dn", "flux_net"), ("flux_up", "flux_dn", "flux_net", "flux_dn_dir")
+
+
+def _maxdiff(a, b, names):
+    return max(float(np.abs(np.float64(getattr(a, n)) - np.float64(getattr(b, n))).max()) for n in names)
+
+
+def test_config0_gray_lw_noscat_single_column():
+    params = RRTMGPParameters()
+    gs = O.setup_gray_as_pr_grid(60, np.array([30.0]), 100000.0, 9000.0, GrayOpticalThicknessSchneider2004(), params,
+                                 np.float64)
+    lb = LwBCs(np.ones((1, 1), order="F"), None)
+    out = rte.solve_lw(rte.NoScatLWRTE(1, 60, np.float64, lb), gs)
+    assert _maxdiff(out, O.solve_lw_gray(gs, lb, twostream=False), LWN) < 1e-9
+
+
+def test_config1_clear_sky_100x60_noscat_f64(tables64):
+    t = tables64
+    as_, lb, sb = S.make_columns(100, 60, np.float64, seed=1, clouds=False, night_fraction=0.1)
+    lw = rte.solve_lw(rte.NoScatLWRTE(100, 60, np.float64, lb), as_, t["lw"])
+    sw = rte.solve_sw(rte.NoScatSWRTE(100, 60, np.float64, sb), as_, t["sw"])
+    assert _maxdiff(lw, O.solve_lw(as_, lb, t["lw"], twostream=False), LWN) < 1e-8
+    assert _maxdiff(sw, O.solve_sw(as_, sb, t["sw"], twostream=False), SWN) < 1e-8
+
+
+def test_config2_cloudy_mcica_128x64_f32(tables32):
+    """Against the Float32 oracle on the same Float32 inputs: with fractional cloudiness a Float64 run of
+    the same case draws different McICA masks wherever a draw falls between the two roundings of 1 - cld_frac,
+    so the F32-vs-F64 comparison is only meaningful for overcast / clear columns (tests/test_gpu_parity.py)."""
+    t = tables32
+    as_, lb, sb = S.make_columns(128, 64, np.float32, seed=2, random_cld_frac=True, cos_zenith=0.86)
+    ref_as = S.make_columns(128, 64, np.float32, seed=2, random_cld_frac=True, cos_zenith=0.86)[0]
+    lw = rte.solve_lw(rte.TwoStreamLWRTE(128, 64, np.float32, lb), as_, t["lw"], t["cld_lw"], seed=7)
+    sw = rte.solve_sw(rte.TwoStreamSWRTE(128, 64, np.float32, sb), as_, t["sw"], t["cld_sw"], seed=7)
+    assert _maxdiff(lw, O.solve_lw(ref_as, lb, t["lw"], t["cld_lw"], seed=7), LWN) < 1e-3
+    assert _maxdiff(sw, O.solve_sw(ref_as, sb, t["sw"], t["cld_sw"], seed=7), SWN) < 2e-2
+    # the McICA sample is the oracle's: identical cloud cover (counts of cloudy g-points)
+    np.testing.assert_array_equal(as_.cloud_state.cld_cover_lw, ref_as.cloud_state.cld_cover_lw)
+    np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, ref_as.cloud_state.cld_cover_sw)
+    assert 0 < as_.cloud_state.cld_cover_lw.max() <= 1
+
+
+def test_config3_allsky_aerosols_4096x73_sharded(tables32):
+    """Eight contiguous shards (what 8 ranks would own) reproduce the single-launch result bit for bit."""
+    t = tables32
+    ncol, nlay = 4096, 73
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=3, aerosols=True, night_fraction=0.1)
+    whole_lw = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb), as_, t["lw"], t["cld_lw"], t["aero_lw"], seed=5)
+    whole_sw = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, np.float32, sb), as_, t["sw"], t["cld_sw"], t["aero_sw"], seed=5)
+    for rank in (0, 3, 7):
+        lo, hi = sharding.shard_range(ncol, rank, 8)
+        a, b_lw, b_sw = (sharding.shard_container(x, lo, hi, ncol) for x in (as_, lb, sb))
+        f = rte.solve_lw(rte.TwoStreamLWRTE(hi - lo, nlay, np.float32, b_lw), a, t["lw"], t["cld_lw"], t["aero_lw"], seed=5,
+                         col_offset=lo)
+        np.testing.assert_array_equal(f.flux_net, whole_lw.flux_net[:, lo:hi])
+        f = rte.solve_sw(rte.TwoStreamSWRTE(hi - lo, nlay, np.float32, b_sw), a, t["sw"], t["cld_sw"], t["aero_sw"], seed=5,
+                         col_offset=lo)
+        np.testing.assert_array_equal(f.flux_dn_dir, whole_sw.flux_dn_dir[:, lo:hi])
+    # oracle on a strided sample
+    idx = slice(0, ncol, 97)
+    sub_as, sub_lb = sharding.shard_container(as_, 0, 1, ncol), sharding.shard_container(lb, 0, 1, ncol)
+    ref = O.solve_lw(sub_as, sub_lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=5)
+    assert np.abs(ref.flux_up[:, 0] - whole_lw.flux_up[:, 0]).max() < 1e-3
+    assert np.all(np.isfinite(whole_sw.flux_net[:, idx]))
+
+
+def test_config4_gcm_scale_shard_of_1m_columns(tables32):
+    """Rank 5's 131 072 columns of the 1 048 576-column problem: size-independent properties plus
+    oracle parity on a sample (the oracle at this size would take minutes)."""
+    t = tables32
+    total, world, rank, nlay = 1_048_576, 8, 5, 64
+    lo, hi = sharding.shard_range(total, rank, world)
+    assert hi - lo == 131_072
+    as_, lb, sb = S.make_columns(hi - lo, nlay, np.float32, seed=2026, col_offset=lo, cos_zenith=0.86)
+    lw = rte.solve_lw(rte.TwoStreamLWRTE(hi - lo, nlay, np.float32, lb), as_, t["lw"], t["cld_lw"], seed=11, col_offset=lo)
+    sw = rte.solve_sw(rte.TwoStreamSWRTE(hi - lo, nlay, np.float32, sb), as_, t["sw"], t["cld_sw"], seed=11, col_offset=lo)
+    for f, names in ((lw, LWN), (sw, SWN)):
+        for n in names:
+            assert np.all(np.isfinite(getattr(f, n)))
+        np.testing.assert_array_equal(f.flux_net, f.flux_up - f.flux_dn)
+    np.testing.assert_allclose(sw.flux_dn[-1], sb.toa_flux * sb.cos_zenith, rtol=2e-5)   # TOA incoming = S0 mu0
+    assert np.all(lw.flux_dn[-1] == 0) and np.all(lw.flux_up[0] > 0)
+    assert np.all(sw.flux_dn_dir <= sw.flux_dn * (1 + 1e-5) + 1e-4)
+    # the same global columns generated and solved on their own (another shard width) give the same bits,
+    # and the oracle agrees on them
+    g0 = lo + 77_777
+    sa, slb, ssb = S.make_columns(48, nlay, np.float32, seed=2026, col_offset=g0, cos_zenith=0.86)
+    f2 = rte.solve_lw(rte.TwoStreamLWRTE(48, nlay, np.float32, slb), sa, t["lw"], t["cld_lw"], seed=11, col_offset=g0)
+    np.testing.assert_array_equal(f2.flux_up, lw.flux_up[:, 77_777:77_777 + 48])
+    ref = O.solve_lw(sa, slb, t["lw"], t["cld_lw"], seed=11, col_offset=g0)
+    assert _maxdiff(f2, ref, LWN) < 1e-3
+    refs = O.solve_sw(sa, ssb, t["sw"], t["cld_sw"], seed=11, col_offset=g0)
+    f3 = rte.solve_sw(rte.TwoStreamSWRTE(48, nlay, np.float32, ssb), sa, t["sw"], t["cld_sw"], seed=11, col_offset=g0)
+    np.testing.assert_array_equal(f3.flux_dn, sw.flux_dn[:, 77_777:77_777 + 48])
+    assert _maxdiff(f3, refs, SWN) < 2e-2
