@@ -741,16 +741,17 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const unsigned o2 = __umul24(row + lk.n_pp * NE + je2, sE) + lb.gk;
     FT k000, k100, k010, k110, q000, q100, q010, q110;
     FT p000 = 0, p100 = 0, p010 = 0, p110 = 0, r000 = 0, r100 = 0, r010 = 0, r110 = 0;
+    // the corner strides are wave-uniform: they go into the scalar base of the load, so that one VGPR
+    // offset serves four loads
+    const char *b0 = lk.arena, *b1 = lk.arena + sE, *b2 = lk.arena + sP, *b3 = lk.arena + sP + sE;
     if (SW) {
-        k000 = ldg<FT>(lk.arena, o1); k100 = ldg<FT>(lk.arena, o1 + sE);
-        k010 = ldg<FT>(lk.arena, o1 + sP); k110 = ldg<FT>(lk.arena, o1 + sP + sE);
-        q000 = ldg<FT>(lk.arena, o2); q100 = ldg<FT>(lk.arena, o2 + sE);
-        q010 = ldg<FT>(lk.arena, o2 + sP); q110 = ldg<FT>(lk.arena, o2 + sP + sE);
+        k000 = ldg<FT>(b0, o1); k100 = ldg<FT>(b1, o1); k010 = ldg<FT>(b2, o1); k110 = ldg<FT>(b3, o1);
+        q000 = ldg<FT>(b0, o2); q100 = ldg<FT>(b1, o2); q010 = ldg<FT>(b2, o2); q110 = ldg<FT>(b3, o2);
     } else {
-        const V2<FT> a = ldg<V2<FT>>(lk.arena, o1), b = ldg<V2<FT>>(lk.arena, o1 + sE);
-        const V2<FT> c = ldg<V2<FT>>(lk.arena, o1 + sP), d = ldg<V2<FT>>(lk.arena, o1 + sP + sE);
-        const V2<FT> e = ldg<V2<FT>>(lk.arena, o2), f = ldg<V2<FT>>(lk.arena, o2 + sE);
-        const V2<FT> g = ldg<V2<FT>>(lk.arena, o2 + sP), h = ldg<V2<FT>>(lk.arena, o2 + sP + sE);
+        const V2<FT> a = ldg<V2<FT>>(b0, o1), b = ldg<V2<FT>>(b1, o1);
+        const V2<FT> c = ldg<V2<FT>>(b2, o1), d = ldg<V2<FT>>(b3, o1);
+        const V2<FT> e = ldg<V2<FT>>(b0, o2), f = ldg<V2<FT>>(b1, o2);
+        const V2<FT> g = ldg<V2<FT>>(b2, o2), h = ldg<V2<FT>>(b3, o2);
         k000 = a.x; k100 = b.x; k010 = c.x; k110 = d.x; q000 = e.x; q100 = f.x; q010 = g.x; q110 = h.x;
         p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
     }
@@ -778,8 +779,8 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
                 const int i = (i0 + j < n) ? i0 + j : n - 1;
                 const unsigned c = __umul24((unsigned)i, cstep);
                 const unsigned x1 = a1 + c, x2 = a2 + c;
-                c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn, x1 + NCb);
-                c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn, x2 + NCb);
+                c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
+                c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
                 sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
             }
 #pragma unroll
