@@ -223,6 +223,8 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         TRY(relayout3(d->rayl_upper, NG, ident, &g.off_rayl[1]));
         TRY(upload_raw<FT>(lk, d->solar_src_scaled, NG, &g.solar_src_scaled));
     }
+    // lanes of bands without minor gases issue dummy loads at [g] and [g + n_contrib] (gas_optics): keep them in bounds
+    arena_piece((size_t)std::max(g.m_ncontrib[0], g.m_ncontrib[1]) + NG + 64);
     RR_CHECK((double)arena.size() * sizeof(FT) < 4.0e9, "gas lookup too large for 32-bit table offsets");
     {
         const FT *dev = nullptr;

@@ -755,39 +755,58 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         k000 = a.x; k100 = b.x; k010 = c.x; k110 = d.x; q000 = e.x; q100 = f.x; q010 = g.x; q110 = h.x;
         p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
     }
+    // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
+    // The first MG intervals are loaded UNCONDITIONALLY, right behind the kmajor corners and before
+    // anything is consumed: one exposed latency per layer, no divergent branch around the common case.
+    // Slots past n re-read interval n-1, a band without minor gases reads the start of the arena
+    // (padded by build_gas); both carry a zero scaling, which leaves the (in-order) sum unchanged.
+    FT tau_minor = FT(0);
+    const int n = lb.m_n(tropo);
+    constexpr int MG = 3;
+    const char *kmn = lk.arena;
+    const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
+    const unsigned a1 = n > 0 ? __umul24(jT * NE + je1, NCb) + lb.gm(tropo) : lb.gE;
+    const unsigned a2 = n > 0 ? __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo) : lb.gE;
+    const unsigned cstep = lb.ngb * E;
+    const FT *ms = sh.mscale + lb.m_st(tropo) * CH + kk;
+    const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
+    {
+        FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
+#pragma unroll
+        for (int j = 0; j < MG; j++) {
+            const int i = j < n ? j : (n > 0 ? n - 1 : 0);
+            const unsigned c = __umul24((unsigned)i, cstep);
+            const unsigned x1 = a1 + c, x2 = a2 + c;
+            c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
+            c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
+            sc[j] = j < n ? ms[i * CH] : FT(0);
+        }
+#ifndef RR_NO_GATHER_WAIT
+        // every gather of this layer has been issued: one wait instead of one per operand
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+#endif
+#pragma unroll
+        for (int j = 0; j < MG; j++)  // interp2d, optics_utils.jl:85-98
+            tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
+    }
+    for (int i0 = MG; i0 < n; i0 += MG) {  // further groups (bands with more than MG minor gases)
+        FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
+#pragma unroll
+        for (int j = 0; j < MG; j++) {
+            const int i = (i0 + j < n) ? i0 + j : n - 1;
+            const unsigned c = __umul24((unsigned)i, cstep);
+            const unsigned x1 = a1 + c, x2 = a2 + c;
+            c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
+            c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
+            sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
+        }
+#pragma unroll
+        for (int j = 0; j < MG; j++)
+            tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
+    }
     const FT tau_major = (cm1 * (omfP * (omfT * (omfe1 * k000 + fe1 * k100)) + fP * (omfT * (omfe1 * k010 + fe1 * k110))) +
                           cm2 * (omfP * (fT * (omfe2 * q000 + fe2 * q100)) + fP * (fT * (omfe2 * q010 + fe2 * q110)))) *
                          col_dry;
-    // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk)
-    FT tau_minor = FT(0);
-    const int n = lb.m_n(tropo);
-    if (n > 0) {
-        const char *kmn = lk.arena;
-        const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
-        const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
-        const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
-        const FT *ms = sh.mscale + lb.m_st(tropo) * CH + kk;
-        const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
-        // groups of MG intervals: every load of a group is in flight before the first use; slots past
-        // n re-read interval n-1 with a zero scaling, which leaves the (in-order) sum unchanged
-        constexpr int MG = 3;
-        const unsigned cstep = lb.ngb * E;
-        for (int i0 = 0; i0 < n; i0 += MG) {
-            FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
-#pragma unroll
-            for (int j = 0; j < MG; j++) {
-                const int i = (i0 + j < n) ? i0 + j : n - 1;
-                const unsigned c = __umul24((unsigned)i, cstep);
-                const unsigned x1 = a1 + c, x2 = a2 + c;
-                c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
-                c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
-                sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
-            }
-#pragma unroll
-            for (int j = 0; j < MG; j++)  // interp2d, optics_utils.jl:85-98
-                tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
-        }
-    }
     if (!SW) {
         pfrac = (omfP * (omfT * (omfe1 * p000 + fe1 * p100)) + fP * (omfT * (omfe1 * p010 + fe1 * p110))) +
                 (omfP * (fT * (omfe2 * r000 + fe2 * r100)) + fP * (fT * (omfe2 * r010 + fe2 * r110)));
