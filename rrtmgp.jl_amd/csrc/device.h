@@ -282,7 +282,7 @@ struct LevelRec {
 template <typename FT>
 struct alignas(32) ChunkFixed {
     V4<FT> eta[CH * NBMAX];  // fe1, fe2, cm1, cm2
-    V4<FT> cld[CH * NBMAX];  // cloud (tau, ssa, g, -) or (absorption tau, -, -, -)
+    V4<FT> cld[CH * NBMAX];  // cloud (tau, tau*ssa, tau*ssa*g, -) or (absorption tau, -, -, -)
     V4<FT> aer[CH * NBMAX];
     FT Blev[(CH + 1) * NBMAX];
     int je[CH * NBMAX];      // je1 | je2 << 8
@@ -463,11 +463,12 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
 }
 
 // ---- optics_utils.jl:189-223 ---------------------------------------------------------------
+// The increment arrives as (t2, t2*s2, (t2*s2)*g2), formed once per (layer, band) by prepare_chunk.
 template <typename FT>
-__device__ __forceinline__ void increment_2stream(FT &t1, FT &s1, FT &g1, FT t2, FT s2, FT g2) {
+__device__ __forceinline__ void increment_2stream(FT &t1, FT &s1, FT &g1, FT t2, FT t2s2, FT t2s2g2) {
     const FT tau = t1 + t2;
-    FT ssa = t1 * s1 + t2 * s2;
-    const FT ssag = m_div(t1 * s1 * g1 + t2 * s2 * g2, m_max(Num<FT>::eps(), ssa));
+    FT ssa = t1 * s1 + t2s2;
+    const FT ssag = m_div(t1 * s1 * g1 + t2s2g2, m_max(Num<FT>::eps(), ssa));
     ssa = m_div(ssa, m_max(Num<FT>::eps(), tau));
     t1 = tau; s1 = ssa; g1 = ssag;
 }
@@ -618,7 +619,9 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     FT g_cl = (tlsg + tisg) / m_max(Num<FT>::eps(), ssa_cl);
                     ssa_cl /= m_max(Num<FT>::eps(), tau_cl);
                     if (delta) delta_scale(tau_cl, ssa_cl, g_cl);
-                    c0 = tau_cl; c1 = ssa_cl; c2 = g_cl;
+                    // stored as (tau, tau*ssa, tau*ssa*g): the products every g-point of the band would form in
+                    // increment_2stream, same operations in the same order
+                    c0 = tau_cl; c1 = tau_cl * ssa_cl; c2 = c1 * g_cl;
                 } else {
                     c0 = (tl - tls) + (ti - tis);  // cloud_optics.jl:45
                 }
@@ -636,7 +639,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                     FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);
                     FT ssa_aero = tsa / m_max(Num<FT>::eps(), ta);
                     if (delta) delta_scale(ta, ssa_aero, g_aero);
-                    a0 = ta; a1 = ssa_aero; a2 = g_aero;
+                    a0 = ta; a1 = ta * ssa_aero; a2 = a1 * g_aero;
                 } else {
                     a0 = ta - tsa;  // aerosol_optics.jl:45
                 }

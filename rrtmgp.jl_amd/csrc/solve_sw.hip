@@ -16,8 +16,10 @@
 namespace rrtmgp {
 
 // sw_2stream_coeffs, src/rte/shortwave_2stream.jl:189-279
+// inv_mu0 = 1 / max(mu0, mu0_min), formed once per column
 template <typename FT>
-__device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, FT &Rdir, FT &Tdir, FT &Rdif, FT &Tdif) {
+__device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, FT inv_mu0, FT &Rdir, FT &Tdir, FT &Rdif,
+                                                  FT &Tdif) {
     const FT gamma1 = (FT(8) - ssa * (FT(5) + FT(3) * g)) * FT(0.25);
     const FT gamma2 = FT(3) * (ssa * (FT(1) - g)) * FT(0.25);
     const FT gamma3 = (FT(2) - (FT(3) * mu0) * g) * FT(0.25);
@@ -32,7 +34,7 @@ __device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, 
     FT RT_term = m_rcp(k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
     Rdif = RT_term * gamma2 * one_minus_e2kt;
     Tdif = RT_term * FT(2) * k * exp_minusktau;
-    const FT T0 = m_exp(-m_div(tau, m_max(mu0, mu0_min<FT>())));
+    const FT T0 = m_exp(-(tau * inv_mu0));
     FT k_mu = k * mu0;
     FT k_mu2 = k_mu * k_mu;
     const FT diff = FT(1) - k_mu2;
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                              FT &Tdif, bool recompute) {
                 t.tau_cum += tau;
                 const FT dir_k = dir_top * m_exp(-t.tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
-                if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, Rdir, Tdir, Rdif, Tdif);
+                if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, inv_mu0, Rdir, Tdir, Rdif, Tdif);
                 const FT s_up = Rdir * t.dir_above, s_dn = Tdir * t.dir_above;
                 const FT den = m_rcp(FT(1) - t.beta * Rdif);
                 sw.at(k, voff) = Tdif * den;                       // U_{k+1} = A U_k + B
