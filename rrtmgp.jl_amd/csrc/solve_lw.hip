@@ -256,6 +256,32 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                             if (k >= 0) { acc[k * NA] += wu[i]; acc[k * NA + 1] = wd[i]; }
                         }
                     }
+                } else if (!BAND && DIAG && DBT == 8) {
+                    // two streams x (up, dn) x 8 levels: one 16-value reduction per stream
+                    FT pa[16], pc[16];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const bool in = kh - j >= 0;
+                        if (in) { F = A[j] * F + B[j]; Fc = Ac[j] * Fc + Bc[j]; }
+                        pa[j] = in ? F * AL[j] * amask : FT(0);
+                        pa[j + 8] = in ? F * amask : FT(0);
+                        pc[j] = in ? Fc * ALc[j] * amask : FT(0);
+                        pc[j + 8] = in ? Fc * amask : FT(0);
+                    }
+                    FT wa[4], wc[4];
+                    wave_sum16(pa, wa);
+                    wave_sum16(pc, wc);
+                    if ((lane & 15) == 15) {  // rows 0, 1: up of levels j = i + 4 r; rows 2, 3: dn of j = i + 4 (r - 2)
+                        const int r = lane >> 4;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int k = kh - (i + 4 * (r & 1));
+                            if (k >= 0) {
+                                if (r < 2) { acc[k * NA] += wa[i]; acc[k * NA + 2] += wc[i]; }
+                                else { acc[k * NA + 1] = wa[i]; acc[k * NA + 3] = wc[i]; }
+                            }
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < DBT; j++) {

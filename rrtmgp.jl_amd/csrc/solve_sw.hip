@@ -257,6 +257,34 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                             }
                         }
                     }
+                } else if (!BAND && DIAG && DBT == 8) {
+                    FT pa[16], pc[16];  // two streams x (U, beta U) x 8 levels: one 16-value reduction per stream
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const bool in = kl + j < nlay;
+                        if (in) { U = A[j] * U + B[j]; Uc = Ac[j] * Uc + Bc[j]; }
+                        pa[j] = in ? U * amask : FT(0);
+                        pa[j + 8] = in ? BE[j] * U * amask : FT(0);
+                        pc[j] = in ? Uc * amask : FT(0);
+                        pc[j + 8] = in ? BEc[j] * Uc * amask : FT(0);
+                    }
+                    FT wa[4], wc[4];
+                    wave_sum16(pa, wa);
+                    wave_sum16(pc, wc);
+                    if ((lane & 15) == 15) {  // rows 0, 1: U sums of entries j = i + 4 r; rows 2, 3: beta U sums
+                        const int r = lane >> 4;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = i + 4 * (r & 1), lev = kl + j + 1;
+                            if (kl + j < nlay) {
+                                if (r < 2) { acc[lev * NA] = wa[i]; acc[lev * NA + 3] = wc[i]; }
+                                else {
+                                    acc[lev * NA + 1] = (acc[lev * NA + 1] + wa[i]) + acc[lev * NA + 2];
+                                    acc[lev * NA + 4] = (acc[lev * NA + 4] + wc[i]) + acc[lev * NA + 5];
+                                }
+                            }
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < DBT; j++) {
