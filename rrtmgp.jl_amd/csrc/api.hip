@@ -55,10 +55,17 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
 // would run in waves of workgroups and leave the chip half empty during the last one.
 int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel) {
     if (lds_bytes > 160 * 1024) return set_error(RRTMGP_EUNSUPPORTED, "column does not fit the 160 KB LDS");
-    RR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int per_cu = 0;
-    RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes));
-    per_cu = std::max(per_cu, 1);
+    const auto key = std::make_pair(kernel, lds_bytes);
+    auto it = ws->occupancy.find(key);
+    if (it == ws->occupancy.end()) {  // once per kernel variant: the two runtime calls cost more than a small solve
+        // the permission is per kernel, not per workspace: always ask for the whole LDS so that workspaces of
+        // different sizes cannot lower each other's limit
+        RR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int n = 0;
+        RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds_bytes));
+        it = ws->occupancy.emplace(key, std::max(n, 1)).first;
+    }
+    const int per_cu = it->second;
     const int cap = ws->n_cu * per_cu;
     return std::max(1, std::min(ncol, cap));
 }

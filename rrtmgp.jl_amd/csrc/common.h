@@ -9,6 +9,8 @@
 #include <stdint.h>
 
 #include <string>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/rrtmgp_hip.h"
@@ -126,6 +128,8 @@ struct rrtmgp_workspace {
     std::vector<rrtmgp::DeviceBuffer> stage;
     // per-(block, level, lane) scratch of the vertical sweeps
     rrtmgp::DeviceBuffer scratch;
+    // resident workgroups per CU of each (kernel, dynamic LDS size) launched so far
+    std::map<std::pair<const void *, size_t>, int> occupancy;
 };
 
 namespace rrtmgp {
