@@ -291,13 +291,15 @@ struct Stager {
     rrtmgp_workspace *ws;
     struct Back { void *host; void *dev; size_t bytes; };
     std::vector<Back> backs;
+    hipStream_t cs = nullptr;  // stream of the copies; the workspace stream unless the pipelined host path says otherwise
+    hipStream_t copy_stream() const { return cs ? cs : ws->stream; }
 
     // input: returns device pointer (copying H2D if mem == host)
     int in(int mem, int slot, const void *p, size_t bytes, const void **out) {
         if (!p) { *out = nullptr; return RRTMGP_OK; }
         if (mem == RRTMGP_MEM_DEVICE) { *out = p; return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
-        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, ws->stream));
+        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
     }
@@ -315,7 +317,7 @@ struct Stager {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
         if (mem == RRTMGP_MEM_DEVICE) { *outp = const_cast<void *>(p); return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
-        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, ws->stream));
+        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *outp = ws->stage[slot].ptr;
         backs.push_back({const_cast<void *>(p), ws->stage[slot].ptr, bytes});
         return RRTMGP_OK;
@@ -324,6 +326,12 @@ struct Stager {
         if (backs.empty()) return RRTMGP_OK;
         for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ws->stream));
         RR_HIP(hipStreamSynchronize(ws->stream));
+        return RRTMGP_OK;
+    }
+    // copies back on the copy stream, no synchronisation (pipelined host path)
+    int copy_back() {
+        for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, copy_stream()));
+        backs.clear();
         return RRTMGP_OK;
     }
 };
@@ -433,13 +441,14 @@ static int check_common(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, int want
 template <typename FT>
 static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                       const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
-                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts, Stager *chunk = nullptr) {
     RR_CHECK(bcs && bcs->sfc_emis, "LwBCs: sfc_emis is required");
     RR_CHECK(!cld || cld->nband == lk.n_bnd, "cloud lookup band count differs from the gas lookup");
     RR_CHECK(!aero || aero->nband == lk.n_bnd, "aerosol lookup band count differs from the gas lookup");
     const int n_angles = opts ? opts->n_gauss_angles : 1;
     RR_CHECK(twostream || (n_angles >= 1 && n_angles <= 4), "n_gauss_angles must be 1..4");
-    Stager st{ws, {}};
+    Stager own{ws, {}};
+    Stager &st = chunk ? *chunk : own;
     DevState<FT> ds;
     TRY(stage_state(st, as, cld != nullptr, aero != nullptr, true, ds));
     const FT *emis, *inc;
@@ -447,21 +456,26 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl, twostream ? (size_t)lk.n_bnd : 0));
+    if (chunk) {  // pipelined host path: the uploads ran on the copy stream
+        RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
+        RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
+    }
     TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, fl, n_angles, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
-    return st.finish();
+    return chunk ? RRTMGP_OK : st.finish();
 }
 
 template <typename FT>
 static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                       const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
-                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+                      const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts, Stager *chunk = nullptr) {
     RR_CHECK(bcs && bcs->cos_zenith && bcs->toa_flux, "SwBCs: cos_zenith and toa_flux are required");
     RR_CHECK(!twostream || (bcs->sfc_alb_direct && bcs->sfc_alb_diffuse), "SwBCs: surface albedos are required");
     RR_CHECK(!cld || cld->nband == lk.n_bnd, "cloud lookup band count differs from the gas lookup");
     RR_CHECK(!aero || aero->nband == lk.n_bnd, "aerosol lookup band count differs from the gas lookup");
     RR_CHECK(flux && flux->flux_dn_dir, "FluxSW: flux_dn_dir is required");
-    Stager st{ws, {}};
+    Stager own{ws, {}};
+    Stager &st = chunk ? *chunk : own;
     DevState<FT> ds;
     TRY(stage_state(st, as, cld != nullptr, aero != nullptr, false, ds));
     const FT *mu0, *toa, *adir, *adif;
@@ -472,9 +486,146 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(st.in(bcs->mem, S_BC3, bcs->sfc_alb_diffuse, (size_t)lk.n_bnd * ncol * E, (const void **)&adif));
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl, twostream ? (size_t)lk.n_bnd : 0));
+    if (chunk) {
+        RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
+        RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
+    }
     TRY(launch_sw<FT>(ws, twostream, lk, cld, aero, ds, mu0, toa, adir, adif, fl, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
-    return st.finish();
+    return chunk ? RRTMGP_OK : st.finish();
+}
+
+// ---- pipelined host path ------------------------------------------------------------------
+// Host-resident callers (the Julia glue with `array_type = Array`) pay 5 KB per column of uploads
+// and 1-2 KB of downloads per solve.  Every per-column array is one contiguous slab per column range
+// (ncol is the slowest dimension), so a large solve is cut into column chunks: chunk c + 1 is uploaded
+// on a copy stream (into the other staging set) while chunk c is being solved, and chunk c - 1's
+// fluxes travel back at the same time.  Results are identical to the single-launch path: columns are
+// independent and the McICA stream is keyed by the global column (col_offset).
+struct ColumnSlice {
+    size_t E, c0;
+    template <typename T>
+    T *adv(T *p, size_t elems_per_col) const {
+        return p ? (T *)((char *)const_cast<typename std::remove_const<T>::type *>(p) + elems_per_col * c0 * E) : nullptr;
+    }
+};
+
+static void slice_state(rrtmgp_atmos_state &a, const ColumnSlice &s, size_t nc) {
+    const size_t nlay = a.nlay, nlev = nlay + 1;
+    a.ncol = (int64_t)nc;
+    a.layerdata = s.adv(a.layerdata, 4 * nlay); a.p_lev = s.adv(a.p_lev, nlev); a.t_lev = s.adv(a.t_lev, nlev);
+    a.t_sfc = s.adv(a.t_sfc, 1); a.lat = s.adv(a.lat, 1);
+    a.vmr_h2o = s.adv(a.vmr_h2o, nlay); a.vmr_o3 = s.adv(a.vmr_o3, nlay);
+    if (a.vmr_kind == RRTMGP_VMR_FULL) a.vmr = s.adv(a.vmr, (size_t)a.ngas * nlay);
+    a.cld_r_eff_liq = s.adv(a.cld_r_eff_liq, nlay); a.cld_r_eff_ice = s.adv(a.cld_r_eff_ice, nlay);
+    a.cld_path_liq = s.adv(a.cld_path_liq, nlay); a.cld_path_ice = s.adv(a.cld_path_ice, nlay);
+    a.cld_frac = s.adv(a.cld_frac, nlay);
+    a.cld_cover_lw = s.adv(a.cld_cover_lw, 1); a.cld_cover_sw = s.adv(a.cld_cover_sw, 1);
+    a.aero_size = s.adv(a.aero_size, RRTMGP_N_AEROSOLS * nlay); a.aero_mass = s.adv(a.aero_mass, RRTMGP_N_AEROSOLS * nlay);
+    a.aod_sw_ext = s.adv(a.aod_sw_ext, 1); a.aod_sw_sca = s.adv(a.aod_sw_sca, 1);
+}
+static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev) {
+    f.flux_up = s.adv(f.flux_up, nlev); f.flux_dn = s.adv(f.flux_dn, nlev); f.flux_net = s.adv(f.flux_net, nlev);
+    f.flux_dn_dir = s.adv(f.flux_dn_dir, nlev);
+    f.clear_flux_up = s.adv(f.clear_flux_up, nlev); f.clear_flux_dn = s.adv(f.clear_flux_dn, nlev);
+    f.clear_flux_net = s.adv(f.clear_flux_net, nlev); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, nlev);
+    o.metric_scaling = s.adv(o.metric_scaling, nlev);
+    o.col_offset += (int64_t)s.c0;
+}
+
+static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, const rrtmgp_flux_out *flux,
+                                  const rrtmgp_solve_opts *opts) {
+    static const bool off = getenv("RRTMGP_HIP_NO_HOST_PIPELINE") != nullptr;
+    if (off || !as || !flux) return false;
+    if (as->mem != RRTMGP_MEM_HOST || bcs_mem != RRTMGP_MEM_HOST || flux->mem != RRTMGP_MEM_HOST) return false;
+    if (flux->layout != RRTMGP_LAYOUT_NLEV_NCOL || flux->band_flux_up || flux->band_flux_dn || flux->band_flux_net) return false;
+    if (opts && opts->metric_scaling && opts->metric_mem != RRTMGP_MEM_HOST) return false;
+    return as->ncol >= 16384;
+}
+
+static int pipeline_resources(rrtmgp_workspace *ws) {
+    if (ws->copy_stream) return RRTMGP_OK;
+    RR_HIP(hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        RR_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
+        RR_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
+    }
+    ws->stage_alt.resize(ws->stage.size());
+    return RRTMGP_OK;
+}
+
+// `solve_chunk(as_c, flux_c, opts_c, slice, stager)` stages and launches one chunk
+template <typename F>
+static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_flux_out *flux,
+                             const rrtmgp_solve_opts *opts, size_t E, F &&solve_chunk) {
+    TRY(pipeline_resources(ws));
+    const size_t ncol = as->ncol, nlev = as->nlay + 1;
+    const int nchunk = (int)std::min<size_t>(8, std::max<size_t>(2, ncol / 32768));
+    RR_HIP(hipStreamSynchronize(ws->stream));  // earlier work of the caller on this workspace
+    Stager prev{ws, {}};
+    prev.cs = ws->copy_stream;
+    int rc = RRTMGP_OK;
+    for (int c = 0; c < nchunk && rc == RRTMGP_OK; c++) {
+        const size_t per = (ncol + nchunk - 1) / nchunk;  // equal chunks, the last one shorter: staging buffers never grow mid-way
+        const size_t c0 = std::min(ncol, per * c), c1 = std::min(ncol, per * (c + 1));
+        if (c1 == c0) break;
+        ColumnSlice sl{E, c0};
+        rrtmgp_atmos_state a = *as;
+        rrtmgp_flux_out f = *flux;
+        rrtmgp_solve_opts o{};
+        if (opts) o = *opts; else o.n_gauss_angles = 1;
+        slice_state(a, sl, c1 - c0);
+        slice_flux(f, o, sl, nlev);
+        std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
+        Stager st{ws, {}};
+        st.cs = ws->copy_stream;
+        rc = solve_chunk(a, f, o, sl, st);
+        if (rc == RRTMGP_OK && hipEventRecord(ws->ev_k[c & 1], ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipEventRecord");
+        // chunk c - 1: its kernel is older than chunk c's, wait for it on the copy stream and bring the fluxes home
+        if (rc == RRTMGP_OK && c > 0) {
+            if (hipStreamWaitEvent(ws->copy_stream, ws->ev_k[(c - 1) & 1], 0) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipStreamWaitEvent");
+            else rc = prev.copy_back();
+        }
+        prev.backs = std::move(st.backs);
+    }
+    if (rc == RRTMGP_OK) {
+        // the last chunk's kernel is the newest work on the compute stream
+        if (hipStreamSynchronize(ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipStreamSynchronize");
+        else rc = prev.copy_back();
+    }
+    (void)hipStreamSynchronize(ws->copy_stream);
+    (void)hipStreamSynchronize(ws->stream);
+    return rc;
+}
+
+template <typename FT>
+static int solve_lw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
+                         const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
+                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (!bcs || bcs->inc_flux || !host_pipeline_applies(as, bcs->mem, flux, opts))
+        return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
+    return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
+                             [&](rrtmgp_atmos_state &a, rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &sl, Stager &st) {
+                                 rrtmgp_lw_bcs b = *bcs;
+                                 b.sfc_emis = sl.adv(b.sfc_emis, (size_t)lk.n_bnd);
+                                 return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, &a, &b, &f, &o, &st);
+                             });
+}
+
+template <typename FT>
+static int solve_sw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
+                         const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
+                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts))
+        return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
+    return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
+                             [&](rrtmgp_atmos_state &a, rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &sl, Stager &st) {
+                                 rrtmgp_sw_bcs b = *bcs;
+                                 b.cos_zenith = sl.adv(b.cos_zenith, 1); b.toa_flux = sl.adv(b.toa_flux, 1);
+                                 b.sfc_alb_direct = sl.adv(b.sfc_alb_direct, (size_t)lk.n_bnd);
+                                 b.sfc_alb_diffuse = sl.adv(b.sfc_alb_diffuse, (size_t)lk.n_bnd);
+                                 return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, &a, &b, &f, &o, &st);
+                             });
 }
 
 // prepare_atmosphere! (update_fluxes.jl:252-281): stage every array the cascade touches as in/out
@@ -698,6 +849,12 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
     (void)hipSetDevice(ws->device);
     (void)hipStreamSynchronize(ws->stream);
     for (auto &b : ws->stage) if (b.ptr) (void)hipFree(b.ptr);
+    for (auto &b : ws->stage_alt) if (b.ptr) (void)hipFree(b.ptr);
+    for (int i = 0; i < 2; i++) {
+        if (ws->ev_in[i]) (void)hipEventDestroy(ws->ev_in[i]);
+        if (ws->ev_k[i]) (void)hipEventDestroy(ws->ev_k[i]);
+    }
+    if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
     if (ws->scratch.ptr) (void)hipFree(ws->scratch.ptr);
     if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);
     if (ws->ev_stop) (void)hipEventDestroy(ws->ev_stop);
@@ -741,7 +898,7 @@ int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *l
                                     const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     const int twostream = 1;
-    return GAS_DISPATCH(ws, solve_lw_t, lookup_lw, cld, aero, as, bcs, flux, opts);
+    return GAS_DISPATCH(ws, solve_lw_host, lookup_lw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
@@ -749,7 +906,7 @@ int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     const int twostream = 0;
-    return GAS_DISPATCH(ws, solve_lw_t, lookup_lw, cld, aero, as, bcs, flux, opts);
+    return GAS_DISPATCH(ws, solve_lw_host, lookup_lw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_lookup *cld,
@@ -757,7 +914,7 @@ int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *l
                                     const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     TRY(check_common(ws, lookup_sw, 1, cld, aero, as));
     const int twostream = 1;
-    return GAS_DISPATCH(ws, solve_sw_t, lookup_sw, cld, aero, as, bcs, flux, opts);
+    return GAS_DISPATCH(ws, solve_sw_host, lookup_sw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_atmos_state *as,
@@ -765,7 +922,7 @@ int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
     TRY(check_common(ws, lookup_sw, 1, nullptr, nullptr, as));
     const int twostream = 0;
     const rrtmgp_lookup *cld = nullptr, *aero = nullptr;
-    return GAS_DISPATCH(ws, solve_sw_t, lookup_sw, cld, aero, as, bcs, flux, opts);
+    return GAS_DISPATCH(ws, solve_sw_host, lookup_sw, cld, aero, as, bcs, flux, opts);
 }
 
 static int check_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const void *bcs, const rrtmgp_flux_out *flux) {

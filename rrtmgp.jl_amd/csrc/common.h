@@ -124,8 +124,11 @@ struct rrtmgp_workspace {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     int n_cu = 0;
-    // staging mirrors for host-memory callers, keyed by slot
-    std::vector<rrtmgp::DeviceBuffer> stage;
+    // staging mirrors for host-memory callers, keyed by slot; the second set and the copy stream serve the
+    // pipelined host path (column chunks: chunk c+1 is uploaded while chunk c is being solved)
+    std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
     // per-(block, level, lane) scratch of the vertical sweeps
     rrtmgp::DeviceBuffer scratch;
     // resident workgroups per CU of each (kernel, dynamic LDS size) launched so far

@@ -367,3 +367,40 @@ def test_wave_sum16_device_unit_test(tmp_path):
                     "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_host_pipeline_matches_device_resident_solve(tables32):
+    """Large host-memory solves are cut into column chunks whose uploads overlap the previous chunk's
+    kernel (api.hip, "pipelined host path").  Same bits as the single-launch device-resident solve,
+    including the McICA sample (keyed by the global column) and the per-column diagnostics."""
+    import torch
+    t = tables32
+    ncol, nlay = 70_001, 12      # 3 chunks, the last one shorter
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=5, aerosols=True, night_fraction=0.2, random_cld_frac=True)
+    metric = np.asfortranarray(np.random.default_rng(0).uniform(0.98, 1.02, (nlay + 1, ncol)).astype(np.float32))
+    host_lw = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
+    host_sw = rte.TwoStreamSWRTE(ncol, nlay, np.float32, sb)
+    from rrtmgp_jl_amd.states import Flux
+    clr = Flux.allocate(ncol, nlay + 1, np.float32, sw=True)
+    f_lw = rte.solve_lw(host_lw, as_, t["lw"], t["cld_lw"], t["aero_lw"], metric_scaling=metric, seed=3, col_offset=1000)
+    f_sw = rte.solve_sw(host_sw, as_, t["sw"], t["cld_sw"], t["aero_sw"], seed=3, col_offset=1000, clear_flux=clr)
+    cover_lw, cover_sw = as_.cloud_state.cld_cover_lw.copy(), as_.cloud_state.cld_cover_sw.copy()
+    aod = as_.aerosol_state.aod_sw_ext.copy()
+    dev = "cuda:0"
+    das, dlb, dsb = as_.to_device(dev), lb.to_device(dev), sb.to_device(dev)
+    d_lw = rte.TwoStreamLWRTE(ncol, nlay, np.float32, dlb, flux_device=dev)
+    d_sw = rte.TwoStreamSWRTE(ncol, nlay, np.float32, dsb, flux_device=dev)
+    dclr = Flux.allocate(ncol, nlay + 1, np.float32, sw=True, device=dev)
+    rte.solve_lw(d_lw, das, t["lw"], t["cld_lw"], t["aero_lw"], metric_scaling=torch.as_tensor(metric.T.copy()).to(dev),
+                 seed=3, col_offset=1000)
+    rte.solve_sw(d_sw, das, t["sw"], t["cld_sw"], t["aero_sw"], seed=3, col_offset=1000, clear_flux=dclr)
+    d_lw.ws.synchronize(); d_sw.ws.synchronize(); torch.cuda.synchronize()
+    for n in LWN:
+        np.testing.assert_array_equal(getattr(f_lw, n), getattr(d_lw.flux.to_host(), n))
+    for n in SWN:
+        np.testing.assert_array_equal(getattr(f_sw, n), getattr(d_sw.flux.to_host(), n))
+        np.testing.assert_array_equal(getattr(clr, n), getattr(dclr.to_host(), n))
+    hs = das.to_host()
+    np.testing.assert_array_equal(cover_lw, hs.cloud_state.cld_cover_lw)
+    np.testing.assert_array_equal(cover_sw, hs.cloud_state.cld_cover_sw)
+    np.testing.assert_array_equal(aod, hs.aerosol_state.aod_sw_ext)
