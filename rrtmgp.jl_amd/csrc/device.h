@@ -248,6 +248,8 @@ struct ColDims {
     int max_int; /* largest minor-interval count of either region */
     int nseg;    /* flux accumulator segments per block: nwaves, or 4 per wave with per-band fluxes */
     int diag;    /* clear-sky fluxes are carried next to the all-sky ones (n_acc doubles) */
+    /* sizes of the small lookup tables mirrored in LDS (TabCache) */
+    int n_t_ref, n_p_ref, n_t_plnk, n_gases_ref, nint0, nint1;
 };
 
 // 4 values read with one ds_read_b128 (Float32) / two (Float64)
@@ -299,6 +301,10 @@ struct ColShared {
     FT *acc;             // [nseg][nlev][n_acc]
     int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
     FT *miscf;           // [0]: pl_sfc_f
+    // TabCache: the small lookup tables the preparation steps index with data-dependent positions, copied once per
+    // workgroup (not per column) so that those dependent reads are LDS round trips instead of L2 ones
+    FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_vmr_ref;
+    int *tab_key_species, *tab_gasdata[2];
 };
 
 template <typename T>
@@ -320,7 +326,34 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
+    s.tab_t_ref = carve<FT>(p, d.n_t_ref);
+    s.tab_ln_p_ref = carve<FT>(p, d.n_p_ref);
+    s.tab_t_planck = carve<FT>(p, d.lw ? d.n_t_plnk : 0);
+    s.tab_vmr_ref = carve<FT>(p, (size_t)2 * d.n_gases_ref * d.n_t_ref);
+    s.tab_key_species = carve<int>(p, 4 * d.nbnd);
+    s.tab_gasdata[0] = carve<int>(p, 4 * (d.nint0 > 0 ? d.nint0 : 1));
+    s.tab_gasdata[1] = carve<int>(p, 4 * (d.nint1 > 0 ? d.nint1 : 1));
     return (size_t)(p - base);
+}
+
+// Fill the TabCache (once per workgroup) and return a lookup view whose small-table pointers are the LDS copies.
+template <typename FT>
+__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < d.n_t_ref; i += nt) sh.tab_t_ref[i] = lk.t_ref[i];
+    for (int i = tid; i < d.n_p_ref; i += nt) sh.tab_ln_p_ref[i] = lk.ln_p_ref[i];
+    if (d.lw) for (int i = tid; i < d.n_t_plnk; i += nt) sh.tab_t_planck[i] = lk.t_planck[i];
+    for (int i = tid; i < 2 * d.n_gases_ref * d.n_t_ref; i += nt) sh.tab_vmr_ref[i] = lk.vmr_ref[i];
+    for (int i = tid; i < 4 * d.nbnd; i += nt) sh.tab_key_species[i] = lk.key_species[i];
+    for (int i = tid; i < 4 * d.nint0; i += nt) sh.tab_gasdata[0][i] = lk.m_gasdata[0][i];
+    for (int i = tid; i < 4 * d.nint1; i += nt) sh.tab_gasdata[1][i] = lk.m_gasdata[1][i];
+    DevGas<FT> v = lk;
+    v.t_ref = sh.tab_t_ref; v.ln_p_ref = sh.tab_ln_p_ref; v.vmr_ref = sh.tab_vmr_ref;
+    if (d.lw) v.t_planck = sh.tab_t_planck;
+    v.key_species = sh.tab_key_species;
+    v.m_gasdata[0] = sh.tab_gasdata[0]; v.m_gasdata[1] = sh.tab_gasdata[1];
+    __syncthreads();
+    return v;
 }
 
 // ---- g-point independent column preparation (lane = layer) --------------------------
@@ -449,15 +482,19 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
     if (tid == 0) {
         if (d.lw) planck_pos(as.t_sfc[col], lk.t_planck, lk.n_t_plnk, sh.misc[d.nwaves], sh.miscf[0]);
         for (int w = 0; w < d.nwaves; w++) sh.misc[w] = 0;
+        sh.misc[d.nwaves + 1] = nlay;  // first cloudy layer (min over layers below)
+        sh.misc[d.nwaves + 2] = -1;    // last cloudy layer (max)
     }
     __syncthreads();
-    if (d.has_cld && tid == 0) {
-        // _get_start / _get_finish, cloud_optics.jl:310-322 (0-based, -1 when clear)
-        int start = -1, finish = -1;
-        for (int k = 0; k < nlay; k++) if (sh.lay[k].cld_frac > FT(0)) { start = k; break; }
-        for (int k = nlay - 1; k >= 0; k--) if (sh.lay[k].cld_frac > FT(0)) { finish = k; break; }
-        sh.misc[d.nwaves + 1] = start;
-        sh.misc[d.nwaves + 2] = finish;
+    if (d.has_cld) {
+        // _get_start / _get_finish, cloud_optics.jl:310-322 (0-based, -1 when clear), one layer per thread
+        for (int k = tid; k < nlay; k += nt)
+            if (sh.lay[k].cld_frac > FT(0)) {
+                atomicMin(&sh.misc[d.nwaves + 1], k);
+                atomicMax(&sh.misc[d.nwaves + 2], k);
+            }
+        __syncthreads();
+        if (tid == 0 && sh.misc[d.nwaves + 1] == nlay) sh.misc[d.nwaves + 1] = -1;
     }
     __syncthreads();
 }

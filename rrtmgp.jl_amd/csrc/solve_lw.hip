@@ -126,9 +126,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                      (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CH - 1) / CH;
+    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk);  // lookup view for the preparation steps
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
-        prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
+        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
 
         uint64_t m0 = 0, m1 = 0;
         if (d.has_cld) {
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, false);
+                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
                 __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, false);
+                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
                 __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
@@ -416,7 +417,9 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
-    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
+    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves;
+    d.n_t_ref = lk.n_t_ref; d.n_p_ref = lk.n_pp - 1; d.n_t_plnk = lk.n_t_plnk; d.n_gases_ref = lk.n_gases;
+    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 4 : 2; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");

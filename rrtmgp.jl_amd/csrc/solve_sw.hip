@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CH - 1) / CH;
+    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk);  // lookup view for the preparation steps
     const bool want_aod = d.has_aero && a.aero.iband_550nm > 0 && a.as.aod_sw_ext != nullptr;
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             store_column(a.fl, sh, d, col, ncol, true, a.lk);
             continue;
         }
-        prepare_column(sh, d, a.lk, &a.cld, &a.aero, a.as, col);
+        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
 
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk;
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, a.lk, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
             }
         }
         __syncthreads();
@@ -353,7 +354,9 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
         RR_CHECK(twostream && fl.band_dn, "per-band fluxes need a two-stream solver and both up/dn buffers");
         if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
     }
-    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
+    d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves;
+    d.n_t_ref = lk.n_t_ref; d.n_p_ref = lk.n_pp - 1; d.n_t_plnk = lk.n_t_plnk; d.n_gases_ref = lk.n_gases;
+    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 6 : 3; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
