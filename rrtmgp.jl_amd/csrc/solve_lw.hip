@@ -80,16 +80,16 @@ struct LwArgs {
 
 // cloud + aerosol increments of one layer for this lane (TwoStream), or their absorption only (OneScalar)
 template <typename FT, bool TWOSTREAM>
-__device__ __forceinline__ void lw_layer_increments(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
+__device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColShared<FT> &sh, const LaneBand &lb, int k,
                                                     int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g) {
     g = FT(0);
     const int r = kk * NBMAX + lb.ibnd;
-    if (a.dims.has_cld && mask_bit(m0, m1, k)) {
+    if (d.has_cld && mask_bit(m0, m1, k)) {
         const V4<FT> c = sh.ch->cld[r];
         if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
         else tau += c.x;
     }
-    if (a.dims.has_aero && sh.lay[k].aero_mask) {
+    if (d.has_aero && sh.lay[k].aero_mask) {
         const V4<FT> c = sh.ch->aer[r];
         if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
         else tau += c.x;
@@ -98,10 +98,11 @@ __device__ __forceinline__ void lw_layer_increments(const LwArgs<FT> &a, const C
 
 // optics of one layer for this lane: gas, then the increments
 template <typename FT, bool TWOSTREAM>
-__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColShared<FT> &sh, const LaneBand &lb, int k,
-                                                int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g, FT &pfrac) {
-    gas_optics<FT, false>(a.lk, sh, lb, k, kk, a.dims.nbnd, tau, ssa, pfrac);
-    lw_layer_increments<FT, TWOSTREAM>(a, sh, lb, k, kk, m0, m1, tau, ssa, g);
+__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColDims &d, const ColShared<FT> &sh,
+                                                const LaneBand &lb, int k, int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa,
+                                                FT &g, FT &pfrac) {
+    gas_optics<FT, false>(a.lk, sh, lb, k, kk, d.nbnd, tau, ssa, pfrac);
+    lw_layer_increments<FT, TWOSTREAM>(d, sh, lb, k, kk, m0, m1, tau, ssa, g);
 }
 
 constexpr int DB = 16;  // levels per batch of the top-down sweeps
@@ -109,12 +110,16 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // DIAG: the clear-sky recurrences (no cloud increment) are carried next to the all-sky ones in
 // the same launch, sharing the gas optics, sources and aerosol record: the one-pass form of
 // AllSkyRadiationWithClearSkyDiagnostics (update_fluxes.jl:39-65), which the reference solves twice.
-template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG>
+// CA: -1 = clouds / aerosols are run-time flags; 0..3 = (clouds | aerosols << 1) known at compile time (the main
+// two-stream instance: absent optics leave no code, no kernel arguments in registers and no lane masks behind).
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
-    carve_shared(sh, smem, a.dims);
-    const ColDims &d = a.dims;
+    ColDims dd = a.dims;
+    if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
+    const ColDims &d = dd;
+    carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool active = tid < a.lk.n_gpt;
@@ -191,11 +196,11 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                         gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
                         tau_c = tau; ssa_c = ssa;
                         cld_k = d.has_cld && mask_bit(m0, m1, k);
-                        lw_layer_increments<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg);
-                        if (cld_k) lw_layer_increments<FT, true>(a, sh, lb, k, kk, 0, 0, tau_c, ssa_c, g_c);
+                        lw_layer_increments<FT, true>(d, sh, lb, k, kk, m0, m1, tau, ssa, gg);
+                        if (cld_k) lw_layer_increments<FT, true>(d, sh, lb, k, kk, 0, 0, tau_c, ssa_c, g_c);
                         else { tau_c = tau; ssa_c = ssa; g_c = gg; }
                     } else {
-                        lw_layer_optics<FT, true>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                        lw_layer_optics<FT, true>(a, d, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
                     }
                     const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
@@ -312,7 +317,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, false>(a, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    lw_layer_optics<FT, false>(a, d, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
                     const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
                     const FT lay_src = sh.ch->Blay[kk * NBMAX + lb.ibnd] * pfrac;
@@ -436,7 +441,10 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     auto kern = !twostream ? lw_solve_kernel<FT, false, false, false>
                 : diag     ? lw_solve_kernel<FT, true, false, true>
-                : fl.band_up ? lw_solve_kernel<FT, true, true, false> : lw_solve_kernel<FT, true, false, false>;
+                : fl.band_up ? lw_solve_kernel<FT, true, true, false>
+                : (cld && aero) ? lw_solve_kernel<FT, true, false, false, 3>
+                : cld  ? lw_solve_kernel<FT, true, false, false, 1>
+                : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT));

@@ -79,12 +79,15 @@ struct SwArgs {
 constexpr int DB = 16;  // levels per batch of the light sweeps
 
 // DIAG: clear-sky recurrences carried next to the all-sky ones (see lw_solve_kernel)
-template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG>
+// CA: see lw_solve_kernel
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     ColShared<FT> sh;
-    carve_shared(sh, smem, a.dims);
-    const ColDims &d = a.dims;
+    ColDims dd = a.dims;
+    if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
+    const ColDims &d = dd;
+    carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const bool active = tid < a.lk.n_gpt;
@@ -369,7 +372,10 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     auto kern = !twostream ? sw_solve_kernel<FT, false, false, false>
                 : diag     ? sw_solve_kernel<FT, true, false, true>
-                : fl.band_up ? sw_solve_kernel<FT, true, true, false> : sw_solve_kernel<FT, true, false, false>;
+                : fl.band_up ? sw_solve_kernel<FT, true, true, false>
+                : (cld && aero) ? sw_solve_kernel<FT, true, false, false, 3>
+                : cld  ? sw_solve_kernel<FT, true, false, false, 1>
+                : aero ? sw_solve_kernel<FT, true, false, false, 2> : sw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
     int rc = scratch_ensure(ws, (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT));
