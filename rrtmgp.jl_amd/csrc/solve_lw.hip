@@ -440,7 +440,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
     }
     auto kern = !twostream ? lw_solve_kernel<FT, false, false, false>
-                : diag     ? lw_solve_kernel<FT, true, false, true>
+                : diag     ? (aero ? lw_solve_kernel<FT, true, false, true, 3> : lw_solve_kernel<FT, true, false, true, 1>)
                 : fl.band_up ? lw_solve_kernel<FT, true, true, false>
                 : (cld && aero) ? lw_solve_kernel<FT, true, false, false, 3>
                 : cld  ? lw_solve_kernel<FT, true, false, false, 1>

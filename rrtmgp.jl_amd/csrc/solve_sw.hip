@@ -371,7 +371,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
     }
     auto kern = !twostream ? sw_solve_kernel<FT, false, false, false>
-                : diag     ? sw_solve_kernel<FT, true, false, true>
+                : diag     ? (aero ? sw_solve_kernel<FT, true, false, true, 3> : sw_solve_kernel<FT, true, false, true, 1>)
                 : fl.band_up ? sw_solve_kernel<FT, true, true, false>
                 : (cld && aero) ? sw_solve_kernel<FT, true, false, false, 3>
                 : cld  ? sw_solve_kernel<FT, true, false, false, 1>
