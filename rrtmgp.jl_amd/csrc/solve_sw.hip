@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     ColShared<FT> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
+    dd.diag = DIAG;  // what the host set, as a constant: the other flux set's pointers are never loaded
+    DevFlux<FT> fl_out = a.fl;
+    if (!BAND) fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
     const ColDims &d = dd;
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
@@ -107,7 +110,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
         const FT mu0 = a.cos_zenith[col];
         const bool day = mu0 > FT(0);
         if (!TWOSTREAM && !day) {  // shortwave_noscat.jl:86-99: nothing runs for night columns
-            store_column(a.fl, sh, d, col, ncol, true, a.lk);
+            store_column(fl_out, sh, d, col, ncol, true, a.lk);
             continue;
         }
         prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 }
             }
             __syncthreads();
-            store_column(a.fl, sh, d, col, ncol, false, a.lk);
+            store_column(fl_out, sh, d, col, ncol, false, a.lk);
             __syncthreads();
             continue;
         }
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             a.as.aod_sw_ext[col] = e;
             a.as.aod_sw_sca[col] = s;
         }
-        store_column(a.fl, sh, d, col, ncol, !day, a.lk);
+        store_column(fl_out, sh, d, col, ncol, !day, a.lk);
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
