@@ -304,6 +304,7 @@ struct ColShared {
     // TabCache: the small lookup tables the preparation steps index with data-dependent positions, copied once per
     // workgroup (not per column) so that those dependent reads are LDS round trips instead of L2 ones
     FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_vmr_ref;
+    FT *tab_vmr_gm;  // VmrGM: the well-mixed vector, [ngas1] with entry 0 = 1 (it does not depend on the column)
     int *tab_key_species, *tab_gasdata[2];
 };
 
@@ -330,6 +331,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
     s.tab_ln_p_ref = carve<FT>(p, d.n_p_ref);
     s.tab_t_planck = carve<FT>(p, d.lw ? d.n_t_plnk : 0);
     s.tab_vmr_ref = carve<FT>(p, (size_t)2 * d.n_gases_ref * d.n_t_ref);
+    s.tab_vmr_gm = carve<FT>(p, d.ngas1);
     s.tab_key_species = carve<int>(p, 4 * d.nbnd);
     s.tab_gasdata[0] = carve<int>(p, 4 * (d.nint0 > 0 ? d.nint0 : 1));
     s.tab_gasdata[1] = carve<int>(p, 4 * (d.nint1 > 0 ? d.nint1 : 1));
@@ -338,8 +340,11 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
 
 // Fill the TabCache (once per workgroup) and return a lookup view whose small-table pointers are the LDS copies.
 template <typename FT>
-__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk) {
+__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk,
+                                                const DevState<FT> &as) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (as.vmr_kind == RRTMGP_VMR_GM)
+        for (int ig = tid; ig < d.ngas1; ig += nt) sh.tab_vmr_gm[ig] = ig == 0 ? FT(1) : ig <= as.ngas ? as.vmr[ig - 1] : FT(0);
     for (int i = tid; i < d.n_t_ref; i += nt) sh.tab_t_ref[i] = lk.t_ref[i];
     for (int i = tid; i < d.n_p_ref; i += nt) sh.tab_ln_p_ref[i] = lk.ln_p_ref[i];
     if (d.lw) for (int i = tid; i < d.n_t_plnk; i += nt) sh.tab_t_planck[i] = lk.t_planck[i];
@@ -459,19 +464,34 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         }
         sh.lay[k] = rec;
     }
-    // gas table: row ig (1-based gas index), row 0 = 1
-    for (int i = tid; i < d.ngas1 * nlay; i += nt) {
-        const int ig = i / nlay, k = i - ig * nlay;
-        FT v;
-        if (ig == 0) v = FT(1);
-        else if (as.vmr_kind == RRTMGP_VMR_GM) {
-            if (ig == 1) v = as.vmr_h2o[(size_t)nlay * col + k];
-            else if (ig == 3) v = as.vmr_o3[(size_t)nlay * col + k];
-            else v = ig <= as.ngas ? as.vmr[ig - 1] : FT(0);
-        } else {
-            v = ig <= as.ngas ? as.vmr[(size_t)(ig - 1) + (size_t)as.ngas * ((size_t)k + (size_t)nlay * col)] : FT(0);
+    // gas table: row ig (1-based gas index), row 0 = 1 (get_vmr, VolumeMixingRatios.jl:91-129)
+    if (as.vmr_kind == RRTMGP_VMR_GM) {
+        // only rows 1 (h2o) and 3 (o3) depend on the layer; the others repeat the well-mixed vector (LDS copy)
+        for (int i = tid; i < d.ngas1 * nlay; i += nt) {
+            const int ig = i / nlay;
+            if (ig != 1 && ig != 3) sh.vmr[i] = sh.tab_vmr_gm[ig];
         }
-        sh.vmr[i] = v;
+        for (int k = tid; k < 2 * nlay; k += nt) {  // both profile rows in one batch of loads
+            const bool o3 = k >= nlay;
+            const int kl = o3 ? k - nlay : k;
+            if ((o3 ? 3 : 1) < d.ngas1) sh.vmr[(o3 ? 3 : 1) * nlay + kl] = (o3 ? as.vmr_o3 : as.vmr_h2o)[(size_t)nlay * col + kl];
+        }
+    } else {
+        // per-gas profiles: 8 independent loads per thread are in flight before the first store
+        const int n = d.ngas1 * nlay;
+        for (int i0 = tid; i0 < n; i0 += 8 * nt) {
+            FT v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * nt, ig = i / nlay, k = i - ig * nlay;
+                v[j] = (i < n && ig >= 1 && ig <= as.ngas)
+                           ? as.vmr[(size_t)(ig - 1) + (size_t)as.ngas * ((size_t)k + (size_t)nlay * col)]
+                           : (ig == 0 ? FT(1) : FT(0));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (i0 + j * nt < n) sh.vmr[i0 + j * nt] = v[j];
+        }
     }
     if (d.lw)
         for (int k = tid; k < nlev; k += nt) {

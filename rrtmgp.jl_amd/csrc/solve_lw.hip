@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                      (unsigned)(blockDim.x * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CH - 1) / CH;
-    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk);  // lookup view for the preparation steps
+    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
         prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CH - 1) / CH;
-    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk);  // lookup view for the preparation steps
+    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
     const bool want_aod = d.has_aero && a.aero.iband_550nm > 0 && a.as.aod_sw_ext != nullptr;
 
     for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
