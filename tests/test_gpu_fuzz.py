@@ -17,55 +17,58 @@ def _maxdiff(a, b, names):
     return max(float(np.abs(np.float64(getattr(a, n)) - np.float64(getattr(b, n))).max()) for n in names)
 
 
+@pytest.mark.parametrize("FT,tol_lw,tol_sw", [(np.float64, 1e-8, 1e-8), (np.float32, 2e-3, 3e-2)])
 @pytest.mark.parametrize("seed", range(32))
-def test_random_configuration(seed):
+def test_random_configuration(seed, FT, tol_lw, tol_sw):
+    """Float32 runs are compared with the Float32 oracle on the same Float32 inputs (same McICA sample); the
+    budgets are those of tests/test_gpu_parity.py for HIP-F32 vs oracle-F32."""
     rng = np.random.default_rng(1000 + seed)
     n_bnd = int(rng.integers(1, 6))
     gpb_lw = [int(x) for x in rng.choice([1, 3, 4, 8, 16, 20], n_bnd)]
     gpb_sw = [int(x) for x in rng.choice([2, 5, 8, 16, 24], n_bnd)]
-    lw = S.make_gas_lookup("lw", seed=seed, n_bnd=n_bnd, gpt_per_bnd=gpb_lw, n_minor_lower=(0, 8), n_minor_upper=(0, 5))
-    sw = S.make_gas_lookup("sw", seed=seed, n_bnd=n_bnd, gpt_per_bnd=gpb_sw, n_minor_lower=(0, 8), n_minor_upper=(0, 5))
-    cl, cs = S.make_cloud_lookup("lw", n_bnd, seed=seed), S.make_cloud_lookup("sw", n_bnd, seed=seed)
-    al, asw = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, seed=seed), S.make_aerosol_lookup("sw", sw.bnd_lims_wn, seed=seed)
+    lw = S.make_gas_lookup("lw", FT, seed=seed, n_bnd=n_bnd, gpt_per_bnd=gpb_lw, n_minor_lower=(0, 8), n_minor_upper=(0, 5))
+    sw = S.make_gas_lookup("sw", FT, seed=seed, n_bnd=n_bnd, gpt_per_bnd=gpb_sw, n_minor_lower=(0, 8), n_minor_upper=(0, 5))
+    cl, cs = S.make_cloud_lookup("lw", n_bnd, FT, seed=seed), S.make_cloud_lookup("sw", n_bnd, FT, seed=seed)
+    al, asw = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, FT, seed=seed), S.make_aerosol_lookup("sw", sw.bnd_lims_wn, FT, seed=seed)
     ncol = int(rng.choice([1, 2, 7, 33, 130]))
     nlay = int(rng.choice([2, 3, 15, 16, 17, 31, 47, 63, 64, 65, 80, 127]))
     clouds, aerosols = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     vmr_kind = str(rng.choice(["gm", "full"]))
-    as_, lb, sb = S.make_columns(ncol, nlay, np.float64, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
+    as_, lb, sb = S.make_columns(ncol, nlay, FT, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
                                  n_bnd_lw=n_bnd, n_bnd_sw=n_bnd, night_fraction=0.3, random_cld_frac=True,
                                  inc_flux_ngpt=lw.n_gpt if rng.integers(0, 2) else 0)
     c_lw, c_sw = (cl, cs) if clouds else (None, None)
     a_lw, a_sw = (al, asw) if aerosols else (None, None)
-    metric = np.asfortranarray(rng.uniform(0.9, 1.1, (nlay + 1, ncol))) if rng.integers(0, 2) else None
+    metric = np.asfortranarray(rng.uniform(0.9, 1.1, (nlay + 1, ncol)).astype(FT)) if rng.integers(0, 2) else None
     kw = dict(seed=int(rng.integers(0, 2**31)), col_offset=int(rng.integers(0, 10**6)), metric_scaling=metric)
-    tag = f"seed={seed} ncol={ncol} nlay={nlay} bands={gpb_lw}/{gpb_sw} clouds={clouds} aerosols={aerosols} {vmr_kind}"
+    tag = f"{np.dtype(FT).name} seed={seed} ncol={ncol} nlay={nlay} bands={gpb_lw}/{gpb_sw} clouds={clouds} aerosols={aerosols} {vmr_kind}"
     # two-stream, with the clear-sky diagnostic in the same launch when there are clouds
-    clr_lw = Flux.allocate(ncol, nlay + 1, np.float64) if clouds else None
-    clr_sw = Flux.allocate(ncol, nlay + 1, np.float64, sw=True) if clouds else None
-    f = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb), as_, lw, c_lw, a_lw, clear_flux=clr_lw, **kw)
-    r_clr = Flux.allocate(ncol, nlay + 1, np.float64) if clouds else None
+    clr_lw = Flux.allocate(ncol, nlay + 1, FT) if clouds else None
+    clr_sw = Flux.allocate(ncol, nlay + 1, FT, sw=True) if clouds else None
+    f = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, clear_flux=clr_lw, **kw)
+    r_clr = Flux.allocate(ncol, nlay + 1, FT) if clouds else None
     r = O.solve_lw(as_, lb, lw, c_lw, a_lw, clear_flux=r_clr, **kw)
-    assert _maxdiff(f, r, LWN) < 1e-8, tag
+    assert _maxdiff(f, r, LWN) < tol_lw, tag
     if clouds:
-        assert _maxdiff(clr_lw, r_clr, LWN) < 1e-8, tag
-    f = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, np.float64, sb), as_, sw, c_sw, a_sw, clear_flux=clr_sw, **kw)
-    r_clr = Flux.allocate(ncol, nlay + 1, np.float64, sw=True) if clouds else None
+        assert _maxdiff(clr_lw, r_clr, LWN) < tol_lw, tag
+    f = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, clear_flux=clr_sw, **kw)
+    r_clr = Flux.allocate(ncol, nlay + 1, FT, sw=True) if clouds else None
     r = O.solve_sw(as_, sb, sw, c_sw, a_sw, clear_flux=r_clr, **kw)
-    assert _maxdiff(f, r, SWN) < 1e-8, tag
+    assert _maxdiff(f, r, SWN) < tol_sw, tag
     if clouds:
-        assert _maxdiff(clr_sw, r_clr, SWN) < 1e-8, tag
+        assert _maxdiff(clr_sw, r_clr, SWN) < tol_sw, tag
     # plain two-stream (the compile-time specialised instances) and the no-scattering solvers
-    assert _maxdiff(rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb), as_, lw, c_lw, a_lw, **kw),
-                    O.solve_lw(as_, lb, lw, c_lw, a_lw, **kw), LWN) < 1e-8, tag
-    assert _maxdiff(rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, np.float64, sb), as_, sw, c_sw, a_sw, **kw),
-                    O.solve_sw(as_, sb, sw, c_sw, a_sw, **kw), SWN) < 1e-8, tag
+    assert _maxdiff(rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, **kw),
+                    O.solve_lw(as_, lb, lw, c_lw, a_lw, **kw), LWN) < tol_lw, tag
+    assert _maxdiff(rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, **kw),
+                    O.solve_sw(as_, sb, sw, c_sw, a_sw, **kw), SWN) < tol_sw, tag
     n_ang = int(rng.integers(1, 5))
-    assert _maxdiff(rte.solve_lw(rte.NoScatLWRTE(ncol, nlay, np.float64, lb, n_gauss_angles=n_ang), as_, lw, c_lw, a_lw, **kw),
-                    O.solve_lw(as_, lb, lw, c_lw, a_lw, twostream=False, n_gauss_angles=n_ang, **kw), LWN) < 1e-8, tag
-    assert _maxdiff(rte.solve_sw(rte.NoScatSWRTE(ncol, nlay, np.float64, sb), as_, sw, **kw),
-                    O.solve_sw(as_, sb, sw, twostream=False, **kw), SWN) < 1e-8, tag
+    assert _maxdiff(rte.solve_lw(rte.NoScatLWRTE(ncol, nlay, FT, lb, n_gauss_angles=n_ang), as_, lw, c_lw, a_lw, **kw),
+                    O.solve_lw(as_, lb, lw, c_lw, a_lw, twostream=False, n_gauss_angles=n_ang, **kw), LWN) < tol_lw, tag
+    assert _maxdiff(rte.solve_sw(rte.NoScatSWRTE(ncol, nlay, FT, sb), as_, sw, **kw),
+                    O.solve_sw(as_, sb, sw, twostream=False, **kw), SWN) < tol_sw, tag
     if clouds:   # identical McICA sample: cloud cover equals the oracle's
-        ref = S.make_columns(ncol, nlay, np.float64, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
+        ref = S.make_columns(ncol, nlay, FT, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
                              n_bnd_lw=n_bnd, n_bnd_sw=n_bnd, night_fraction=0.3, random_cld_frac=True)[0]
         O.solve_lw(ref, lb, lw, c_lw, a_lw, **kw)
         np.testing.assert_array_equal(as_.cloud_state.cld_cover_lw, ref.cloud_state.cld_cover_lw)
