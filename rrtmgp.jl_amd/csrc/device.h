@@ -638,6 +638,19 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         const int b = u / CH, kk = u % CH, k = k0 + kk;  // CH is a power of two
         if (kk >= kn) continue;
         const int t = kk * NBMAX + b;
+        // Planck band sources at levels k0 .. k0 + kn (interp1d_equispaced, compute_optical_props.jl:180-186): the
+        // table reads are issued first so that their latency is covered by the rest of the task; the task of the
+        // chunk's last layer also does the level above it
+        FT pl0 = FT(0), pl1 = FT(0), pt0 = FT(0), pt1 = FT(0);
+        const bool top_too = d.lw && kk == kn - 1;
+        if (d.lw) {
+            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lev[k].loc;
+            pl0 = tp[0]; pl1 = tp[1];
+            if (top_too) {
+                const FT *tq = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lev[k + 1].loc;
+                pt0 = tq[0]; pt1 = tq[1];
+            }
+        }
         const int li = sh.lay[k].idx;
         const int jT = li & 0xff, tropo = li >> 16;
         const int ig0 = lk.key_species[0 + 2 * (tropo + 2 * b)], ig1 = lk.key_species[1 + 2 * (tropo + 2 * b)];
@@ -661,6 +674,10 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         }
         sh.ch->je[t] = je[0] | (je[1] << 8);
         sh.ch->eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
+        if (d.lw) {
+            sh.ch->Blev[t] = pl0 * (FT(1) - sh.lev[k].f) + pl1 * sh.lev[k].f;
+            if (top_too) sh.ch->Blev[(kk + 1) * NBMAX + b] = pt0 * (FT(1) - sh.lev[k + 1].f) + pt1 * sh.lev[k + 1].f;
+        }
         if (d.lw && !d.twostream) {  // layer sources: no-scattering solver only (Blay is not allocated otherwise)
             const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lay[k].pl_lay_loc;
             sh.ch->Blay[t] = tp[0] * (FT(1) - sh.lay[k].pl_lay_f) + tp[1] * sh.lay[k].pl_lay_f;
@@ -727,13 +744,6 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
         }
         sh.mscale[i * CH + kk] = scaling;
     }
-    if (d.lw)  // Planck band sources at levels k0 .. k0 + kn  (interp1d_equispaced, compute_optical_props.jl:180-186)
-        for (int u = tid; u < 2 * CH * nb; u += nt) {
-            const int b = u / (2 * CH), kk = u % (2 * CH), lev = k0 + kk;
-            if (kk > kn) continue;
-            const FT *tp = lk.tot_planck + (size_t)lk.n_t_plnk * b + sh.lev[lev].loc;
-            sh.ch->Blev[kk * NBMAX + b] = tp[0] * (FT(1) - sh.lev[lev].f) + tp[1] * sh.lev[lev].f;
-        }
 }
 
 // ---- per-lane band constants ---------------------------------------------------------
