@@ -75,12 +75,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
     _lib.require_gpu()
+    # RRTMGP_BENCH_BACKEND=gloo + RRTMGP_BENCH_SHARE_GPU=1 is a test hook: several ranks on ONE GPU, to exercise the
+    # multi-process path (barrier, MAX over ranks, rank-0 report) where only one device exists.  Never for numbers.
+    backend = os.environ.get("RRTMGP_BENCH_BACKEND", "nccl")
+    if os.environ.get("RRTMGP_BENCH_SHARE_GPU"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     ft = np.float32 if args.dtype == "f32" else np.float64
     ncol, nlay = args.ncol, args.nlay
@@ -142,7 +150,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -86,3 +86,27 @@ def test_world_size_2_gloo_matches_unsharded():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, 2.0), (1, True, 2.0)]
+
+
+@pytest.mark.gpu
+def test_bench_multi_process_path_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), exercised with two
+    ranks SHARING the only GPU of the test box over gloo (bench.py test hook): barrier, MAX over ranks, one JSON
+    line from rank 0 with the whole-job column count."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RRTMGP_BENCH_BACKEND="gloo", RRTMGP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--ncol", "4096", "--cpu-sample", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "columns/s" and d["steps"] == 2
+    assert d["config"]["ncol_per_gpu"] == 4096
+    assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
