@@ -27,7 +27,8 @@
  *    rrtmgp_hip_last_error() gives the message.  Like the reference kernels,
  *    out-of-range physical inputs are clamped, never rejected.
  *  - A workspace may be used by one host thread at a time; different
- *    workspaces are independent.  Calls are stream-ordered on the workspace
+ *    workspaces are independent and may be driven from different host threads
+ *    concurrently (tests/test_abi_contracts.py).  Calls are stream-ordered on the workspace
  *    stream and block until results are in the caller's arrays only when the
  *    arrays are host memory.
  */
@@ -384,6 +385,49 @@ int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state
  * (grid_adaptation.jl:147-156, 215-227); col_dry does not exist. */
 int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
                                        const rrtmgp_params *params, const rrtmgp_prepare_opts *opts);
+
+/* ---- several GPUs from ONE host process (SURVEY.md §8(b) "Threading", §8(e)) ---------------
+ *
+ * The reference shards columns over devices above its API (one ClimaComms context per rank);
+ * a Julia host that owns all columns in one process gets the same contiguous-range sharding
+ * behind the C ABI instead:
+ *
+ *  - `*_lookup_create_multi` uploads one replica of the lookup per DISTINCT device of
+ *    `device_ids`; the returned handle stands for all of them and is destroyed by
+ *    rrtmgp_hip_lookup_destroy.
+ *  - `rrtmgp_hip_workspace_create_multi` creates one shard per entry of `device_ids` (an id
+ *    may repeat: several shards, each with its own stream, on one GPU).  Shard s owns the
+ *    contiguous global columns [s*ncol/ndev, (s+1)*ncol/ndev); since ncol is the slowest
+ *    dimension of every state / boundary / flux array, each shard's slab is contiguous.
+ *  - Every solver / preparation entry point accepts such a workspace: the call runs the
+ *    shards concurrently (one host thread + one stream per shard), sets `col_offset` per
+ *    shard so that the McICA stream stays keyed by the global column, and returns when every
+ *    shard's results are in the caller's arrays.  The bits are those of a single launch.
+ *  - Arrays must be host memory (RRTMGP_MEM_HOST) unless every shard is on the same device
+ *    as the pointers.  Not shardable in one call, rejected with RRTMGP_EUNSUPPORTED when
+ *    ndev > 1: flux layout RRTMGP_LAYOUT_NCOL_NLEV, LwBCs.inc_flux (both have ncol as the
+ *    FASTEST dimension) and per-band fluxes.
+ *  - Host arrays are page-locked on first use (hipHostRegister, cached per workspace by
+ *    address and size, released by workspace_destroy) so that the per-shard uploads and
+ *    downloads are true asynchronous DMA; RRTMGP_HIP_NO_HOST_REGISTER=1 turns this off.
+ */
+int rrtmgp_hip_gas_lookup_create_multi(const rrtmgp_gas_lookup_desc *desc, const int32_t *device_ids, int ndev,
+                                       rrtmgp_lookup **out);
+int rrtmgp_hip_cloud_lookup_create_multi(const rrtmgp_cloud_lookup_desc *desc, const int32_t *device_ids, int ndev,
+                                         rrtmgp_lookup **out);
+int rrtmgp_hip_aerosol_lookup_create_multi(const rrtmgp_aerosol_lookup_desc *desc, const int32_t *device_ids, int ndev,
+                                           rrtmgp_lookup **out);
+int rrtmgp_hip_workspace_create_multi(const int32_t *device_ids, int ndev, int64_t ncol, int64_t nlay, int32_t ftype,
+                                      rrtmgp_workspace **out);
+/* Number of shards of a workspace (1 for a single-device workspace). */
+int rrtmgp_hip_workspace_shards(const rrtmgp_workspace *ws);
+
+/* ---- allocation accounting (zero-allocation contract, update_fluxes.jl:215-218) ------------ */
+
+/* Device allocations (hipMalloc) and host registrations (hipHostRegister) the library has made
+ * since it was loaded, all workspaces and lookups together.  A warm solve must not change them:
+ * tests/test_abi_contracts.py. */
+int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, int64_t *host_registrations);
 
 /* ---- McICA stream -------------------------------------------------------- */
 

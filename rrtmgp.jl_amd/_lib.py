@@ -9,7 +9,9 @@ import subprocess
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libhip_rrtmgp.so")
+# RRTMGP_HIP_LIBRARY selects another build of the same library (the IEEE-Float32 build
+# `libhip_rrtmgp_precise.so`, or an A/B variant under variants/); the default is the shipped one.
+SO_PATH = os.environ.get("RRTMGP_HIP_LIBRARY") or os.path.join(_HERE, "libhip_rrtmgp.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
@@ -48,6 +50,16 @@ EXPORTS = {
                                                 C.POINTER(_abi.PrepareOpts)]),
     "rrtmgp_hip_prepare_atmosphere_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), C.POINTER(_abi.Params),
                                                      C.POINTER(_abi.PrepareOpts)]),
+    "rrtmgp_hip_gas_lookup_create_multi": (C.c_int, [C.POINTER(_abi.GasLookupDesc), C.POINTER(C.c_int32), C.c_int,
+                                                     C.POINTER(_P)]),
+    "rrtmgp_hip_cloud_lookup_create_multi": (C.c_int, [C.POINTER(_abi.CloudLookupDesc), C.POINTER(C.c_int32), C.c_int,
+                                                       C.POINTER(_P)]),
+    "rrtmgp_hip_aerosol_lookup_create_multi": (C.c_int, [C.POINTER(_abi.AerosolLookupDesc), C.POINTER(C.c_int32), C.c_int,
+                                                         C.POINTER(_P)]),
+    "rrtmgp_hip_workspace_create_multi": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int64, C.c_int64, C.c_int32,
+                                                    C.POINTER(_P)]),
+    "rrtmgp_hip_workspace_shards": (C.c_int, [_P]),
+    "rrtmgp_hip_allocation_counts": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rrtmgp_hip_version": (C.c_char_p, []),
@@ -110,6 +122,13 @@ def last_error() -> str:
 def check(rc: int, what: str):
     if rc != 0:
         raise RRTMGPHipError(f"{what}: {_abi.ERRORS.get(rc, rc)}: {last_error()}")
+
+
+def allocation_counts():
+    """(hipMalloc calls, hipFree calls, hipHostRegister calls) the library has made since it was loaded."""
+    a, f, r = C.c_int64(), C.c_int64(), C.c_int64()
+    check(lib().rrtmgp_hip_allocation_counts(C.byref(a), C.byref(f), C.byref(r)), "allocation_counts")
+    return a.value, f.value, r.value
 
 
 def require_gpu() -> int:

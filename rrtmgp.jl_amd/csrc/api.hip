@@ -1,9 +1,11 @@
 // api.hip — host side of the C ABI declared in include/rrtmgp_hip.h:
 // lookup re-layout + upload, workspaces, host<->HBM staging, solver dispatch.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 #include "device.h"
@@ -17,6 +19,62 @@ int set_error(int code, const std::string &msg) {
     return code;
 }
 
+const std::string &last_error_string() { return g_last_error; }
+
+static std::atomic<int64_t> g_dev_allocs{0}, g_dev_frees{0}, g_host_regs{0};
+hipError_t rr_malloc(void **p, size_t bytes) {
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) g_dev_allocs++;
+    return e;
+}
+hipError_t rr_free(void *p) {
+    g_dev_frees++;
+    return hipFree(p);
+}
+
+// Host arrays handed over with RRTMGP_MEM_HOST are page-locked the first time they are seen, so that the
+// hipMemcpyAsync calls below are real asynchronous DMA (from pageable memory the runtime stages through its own
+// bounce buffers and the "asynchronous" copy blocks the host thread).  A host model keeps its state arrays for the
+// whole run, so this happens once per array: the registry is process-wide, keyed by address range, and a range
+// inside a registered one (a shard's or a chunk's slab of the same array) counts as registered.  Entries belong to
+// the workspace that made them and are released by its destroy.  Any failure (memory that cannot be registered, a
+// range straddling an earlier registration) leaves the array pageable: slower, still correct.
+struct PinEntry { size_t bytes; rrtmgp_workspace *owner; };
+static std::mutex g_pin_mu;
+static std::map<const char *, PinEntry> g_pins;
+bool host_pin(rrtmgp_workspace *ws, const void *ptr, size_t bytes) {
+    static const bool off = getenv("RRTMGP_HIP_NO_HOST_REGISTER") != nullptr;
+    if (off || !ptr || bytes < (1u << 16)) return false;  // small arrays: not worth a registration
+    const char *p = (const char *)ptr;
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    auto it = g_pins.upper_bound(p);
+    if (it != g_pins.begin()) {
+        auto prev = std::prev(it);
+        if (p + bytes <= prev->first + prev->second.bytes) return true;   // inside a registered range
+        if (p < prev->first + prev->second.bytes) return false;           // straddles one
+    }
+    if (it != g_pins.end() && it->first < p + bytes) return false;        // would swallow a later one
+    if (g_pins.size() >= 1024) return false;
+    if (hipHostRegister(const_cast<char *>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_host_regs++;
+    g_pins.emplace(p, PinEntry{bytes, ws});
+    return true;
+}
+void host_unpin_all(rrtmgp_workspace *ws) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    for (auto it = g_pins.begin(); it != g_pins.end();) {
+        if (it->second.owner == ws) {
+            (void)hipHostUnregister(const_cast<char *>(it->first));
+            it = g_pins.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     char buf[512];
     snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
@@ -27,10 +85,10 @@ int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes) {
     if ((int)ws->stage.size() <= slot) ws->stage.resize(slot + 1);
     DeviceBuffer &b = ws->stage[slot];
     if (b.bytes >= bytes && b.ptr) return RRTMGP_OK;
-    if (b.ptr) RR_HIP(hipFree(b.ptr));
+    if (b.ptr) RR_HIP(rr_free(b.ptr));
     b.ptr = nullptr;
     b.bytes = 0;
-    RR_HIP(hipMalloc(&b.ptr, bytes ? bytes : 16));
+    RR_HIP(rr_malloc(&b.ptr, bytes ? bytes : 16));
     b.bytes = bytes;
     return RRTMGP_OK;
 }
@@ -39,11 +97,11 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
     if (ws->scratch.bytes >= bytes && ws->scratch.ptr) return RRTMGP_OK;
     if (ws->scratch.ptr) {
         RR_HIP(hipStreamSynchronize(ws->stream));
-        RR_HIP(hipFree(ws->scratch.ptr));
+        RR_HIP(rr_free(ws->scratch.ptr));
     }
     ws->scratch.ptr = nullptr;
     ws->scratch.bytes = 0;
-    RR_HIP(hipMalloc(&ws->scratch.ptr, bytes));
+    RR_HIP(rr_malloc(&ws->scratch.ptr, bytes));
     ws->scratch.bytes = bytes;
     return RRTMGP_OK;
 }
@@ -75,7 +133,7 @@ template <typename T>
 static int upload(rrtmgp_lookup *lk, const std::vector<T> &h, const T **out) {
     void *d = nullptr;
     const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
-    RR_HIP(hipMalloc(&d, bytes));
+    RR_HIP(rr_malloc(&d, bytes));
     lk->allocs.push_back(d);
     if (!h.empty()) RR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = (const T *)d;
@@ -123,13 +181,13 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         *off = (unsigned)(at * sizeof(FT));
         return RRTMGP_OK;
     };
-    // (n_eta, n_t, n) -> [t][eta][perm(n)]
-    auto relayout3 = [&](const void *src, int64_t n, const std::vector<int64_t> &dst_of_src, unsigned *off) -> int {
+    // (n_eta, n_t, n) -> [t][eta][row], element c of the source at position dst_of_src[c] < row (the rest stays 0)
+    auto relayout3 = [&](const void *src, int64_t n, int64_t row, const std::vector<int64_t> &dst_of_src, unsigned *off) -> int {
         const FT *s = (const FT *)src;
-        const size_t at = arena_piece((size_t)NE * NT * std::max<int64_t>(n, 1));
+        const size_t at = arena_piece((size_t)NE * NT * row);
         for (int64_t c = 0; c < n; c++)
             for (int64_t t = 0; t < NT; t++)
-                for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * n + dst_of_src[c]] = s[e + NE * (t + NT * c)];
+                for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * row + dst_of_src[c]] = s[e + NE * (t + NT * c)];
         *off = (unsigned)(at * sizeof(FT));
         return RRTMGP_OK;
     };
@@ -186,13 +244,22 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         for (int64_t i = 0; i < m->n_min_absrb; i++)
             RR_CHECK(gd[4 * i] >= 0 && gd[4 * i] < d->n_gases && gd[4 * i + 1] >= 0 && gd[4 * i + 1] < d->n_gases,
                      "minor gas index out of range");
-        // reference order: contributor (gpt_st[g] - 1) + i ; device order: koff[b] + i*ng_b + (g - lo_b)
+        // reference order: contributor (gpt_st[g] - 1) + i.  Device order: the contributors of a g-point come in
+        // groups of MINOR_GROUP = 4 that sit next to each other, so that ONE 16-byte (Float32) load per interpolation
+        // corner brings 4 contributors:   koff[b] + ((i / 4) * ng_b + (g - lo_b)) * 4 + i % 4
+        // (a band with n_b contributors per g-point owns ceil(n_b / 4) groups; the padding entries are 0 and
+        // carry a zero scaling).  The scalings of a layer are laid out the same way (slot = 4 * group + i % 4).
         std::vector<int64_t> dst(std::max<int64_t>(m->n_contrib, 1), 0);
+        std::vector<int> st4(NB, 0), slot_int;
         int64_t off = 0;
         for (int64_t b = 0; b < NB; b++) {
             const int64_t nb = bst[b + 1] - bst[b];
             RR_CHECK(nb >= 0, "minor bnd_st must be non-decreasing");
+            // at least one group per band: a band without contributors reads its own all-zero group with zero scalings
+            const int64_t ngrp = std::max<int64_t>(1, (nb + MINOR_GROUP - 1) / MINOR_GROUP);
             koff[b] = (int)off;
+            st4[b] = (int)slot_int.size();
+            for (int64_t i = 0; i < ngrp * MINOR_GROUP; i++) slot_int.push_back(i < nb ? (int)(bst[b] + i) : -1);
             lk->max_minor = std::max<int>(lk->max_minor, (int)nb);
             for (int64_t gi = 0; gi < ng[b]; gi++) {
                 const int64_t gq = lo[b] + gi;
@@ -200,25 +267,24 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
                 for (int64_t i = 0; i < nb; i++) {
                     const int64_t src = m->gpt_st[gq] - 1 + i;
                     RR_CHECK(src >= 0 && src < m->n_contrib, "minor contributor index out of range");
-                    dst[src] = off + i * ng[b] + gi;
+                    dst[src] = off + ((i / MINOR_GROUP) * ng[b] + gi) * MINOR_GROUP + i % MINOR_GROUP;
                 }
             }
-            off += nb * ng[b];
+            off += ngrp * ng[b] * MINOR_GROUP;
         }
-        RR_CHECK(off == m->n_contrib || m->n_contrib == 0 || off <= m->n_contrib, "minor contributor count mismatch");
-        g.m_ncontrib[r] = (int)std::max<int64_t>(m->n_contrib, 1);
-        RR_CHECK(m->n_min_absrb <= 255, "more than 255 minor-gas intervals per region are not supported");
+        const int64_t row = off;
+        g.m_ncontrib[r] = (int)row;
+        RR_CHECK(m->n_min_absrb <= 255 && slot_int.size() <= 1020, "more than 255 minor-gas intervals per region are not supported");
         g.m_nint[r] = (int)m->n_min_absrb;
-        lk->max_int = std::max<int>(lk->max_int, (int)m->n_min_absrb);
+        g.m_nslot[r] = (int)slot_int.size();
+        lk->max_int = std::max<int>(lk->max_int, (int)slot_int.size());
         TRY(upload(lk, bst, &g.m_bnd_st[r]));
         TRY(upload(lk, gd, &g.m_gasdata[r]));
         TRY(upload(lk, koff, &g.m_koff[r]));
-        if (m->n_contrib > 0) {
-            RR_CHECK(m->kminor, "minor lookup: missing kminor");
-            TRY(relayout3(m->kminor, m->n_contrib, dst, &g.off_kminor[r]));
-        } else {
-            g.off_kminor[r] = (unsigned)(arena_piece((size_t)NE * NT) * sizeof(FT));
-        }
+        TRY(upload(lk, st4, &g.m_st4[r]));
+        TRY(upload(lk, slot_int, &g.m_slot_int[r]));
+        RR_CHECK(m->n_contrib == 0 || m->kminor, "minor lookup: missing kminor");
+        TRY(relayout3(m->kminor, m->n_contrib, row, dst, &g.off_kminor[r]));
     }
     g.off_rayl[0] = g.off_rayl[1] = 0;
     g.solar_src_scaled = nullptr;
@@ -226,12 +292,11 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         RR_CHECK(d->rayl_lower && d->rayl_upper && d->solar_src_scaled, "SW lookup: missing Rayleigh / solar tables");
         std::vector<int64_t> ident(NG);
         for (int64_t i = 0; i < NG; i++) ident[i] = i;
-        TRY(relayout3(d->rayl_lower, NG, ident, &g.off_rayl[0]));
-        TRY(relayout3(d->rayl_upper, NG, ident, &g.off_rayl[1]));
+        TRY(relayout3(d->rayl_lower, NG, NG, ident, &g.off_rayl[0]));
+        TRY(relayout3(d->rayl_upper, NG, NG, ident, &g.off_rayl[1]));
         TRY(upload_raw<FT>(lk, d->solar_src_scaled, NG, &g.solar_src_scaled));
     }
-    // lanes of bands without minor gases issue dummy loads at [g] and [g + n_contrib] (gas_optics): keep them in bounds
-    arena_piece((size_t)std::max(g.m_ncontrib[0], g.m_ncontrib[1]) + NG + 64);
+    arena_piece(64);  // keeps the last table off the end of the allocation
     RR_CHECK((double)arena.size() * sizeof(FT) < 4.0e9, "gas lookup too large for 32-bit table offsets");
     {
         const FT *dev = nullptr;
@@ -259,6 +324,7 @@ static int build_aero(rrtmgp_lookup *lk, const rrtmgp_aerosol_lookup_desc *d, De
                  d->black_carbon && d->organic_carbon_rh && d->organic_carbon,
              "aerosol lookup: missing table");
     RR_CHECK(d->nbin >= 1 && d->nbin <= 255 && d->nrh >= 2 && d->nband >= 1, "bad aerosol lookup dimensions");
+    RR_CHECK(d->iband_550nm >= 0 && d->iband_550nm <= d->nband, "iband_550nm must be 0 (none) or a band index");
     a.nband = (int)d->nband; a.nbin = (int)d->nbin; a.nrh = (int)d->nrh; a.iband_550nm = (int)d->iband_550nm;
     TRY(upload_raw<FT>(lk, d->size_bin_limits, 2 * d->nbin, &a.size_bin_limits));
     TRY(upload_raw<FT>(lk, d->rh_levels, d->nrh, &a.rh_levels));
@@ -292,11 +358,19 @@ struct Stager {
     struct Back { void *host; void *dev; size_t bytes; };
     std::vector<Back> backs;
     hipStream_t cs = nullptr;  // stream of the copies; the workspace stream unless the pipelined host path says otherwise
+    bool pin_only = false;     // registration pass over the caller's WHOLE host arrays: no copies, no device memory
     hipStream_t copy_stream() const { return cs ? cs : ws->stream; }
+    bool pin(int mem, const void *p, size_t bytes, void **out) {
+        if (!pin_only) return false;
+        if (mem == RRTMGP_MEM_HOST) host_pin(ws, p, bytes);
+        *out = nullptr;
+        return true;
+    }
 
     // input: returns device pointer (copying H2D if mem == host)
     int in(int mem, int slot, const void *p, size_t bytes, const void **out) {
         if (!p) { *out = nullptr; return RRTMGP_OK; }
+        if (pin(mem, p, bytes, const_cast<void **>(out))) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *out = p; return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
         RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
@@ -306,6 +380,7 @@ struct Stager {
     // output: returns device pointer; host copies are done by finish()
     int out(int mem, int slot, void *p, size_t bytes, void **outp) {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
+        if (pin(mem, p, bytes, outp)) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *outp = p; return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
         *outp = ws->stage[slot].ptr;
@@ -315,6 +390,7 @@ struct Stager {
     // read AND written: staged in, copied back by finish()
     int inout(int mem, int slot, const void *p, size_t bytes, void **outp) {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
+        if (pin(mem, p, bytes, outp)) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *outp = const_cast<void *>(p); return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
         RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
@@ -337,7 +413,8 @@ struct Stager {
 };
 
 template <typename FT>
-static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, bool use_aero, bool lw, DevState<FT> &d) {
+static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, bool use_aero, bool lw, DevState<FT> &d,
+                       int64_t nrghice = 1) {
     const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1;
     RR_CHECK(as->layerdata && as->t_sfc && as->vmr, "atmospheric state: missing array");
     RR_CHECK(!lw || as->t_lev, "atmospheric state: t_lev is required for longwave");
@@ -361,7 +438,7 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
     if (use_cld) {
         RR_CHECK(as->cld_frac && as->cld_r_eff_liq && as->cld_r_eff_ice && as->cld_path_liq && as->cld_path_ice,
                  "cloud lookup given but the state has no CloudState");
-        RR_CHECK(as->ice_rgh >= 1, "ice_rgh must be >= 1");
+        RR_CHECK(as->ice_rgh >= 1 && as->ice_rgh <= nrghice, "ice_rgh must be in 1..nrghice of the cloud lookup");
         TRY(st.in(mem, S_CLD_RL, as->cld_r_eff_liq, nlay * ncol * E, (const void **)&d.cld_r_eff_liq));
         TRY(st.in(mem, S_CLD_RI, as->cld_r_eff_ice, nlay * ncol * E, (const void **)&d.cld_r_eff_ice));
         TRY(st.in(mem, S_CLD_PL, as->cld_path_liq, nlay * ncol * E, (const void **)&d.cld_path_liq));
@@ -450,12 +527,13 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     Stager own{ws, {}};
     Stager &st = chunk ? *chunk : own;
     DevState<FT> ds;
-    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, true, ds));
+    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, true, ds, cld ? cld->nrghice : 1));
     const FT *emis, *inc;
     TRY(st.in(bcs->mem, S_BC0, bcs->sfc_emis, (size_t)lk.n_bnd * as->ncol * sizeof(FT), (const void **)&emis));
     TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl, twostream ? (size_t)lk.n_bnd : 0));
+    if (st.pin_only) return RRTMGP_OK;
     if (chunk) {  // pipelined host path: the uploads ran on the copy stream
         RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
@@ -477,7 +555,7 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     Stager own{ws, {}};
     Stager &st = chunk ? *chunk : own;
     DevState<FT> ds;
-    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, false, ds));
+    TRY(stage_state(st, as, cld != nullptr, aero != nullptr, false, ds, cld ? cld->nrghice : 1));
     const FT *mu0, *toa, *adir, *adif;
     const size_t E = sizeof(FT), ncol = as->ncol;
     TRY(st.in(bcs->mem, S_BC0, bcs->cos_zenith, ncol * E, (const void **)&mu0));
@@ -486,6 +564,7 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(st.in(bcs->mem, S_BC3, bcs->sfc_alb_diffuse, (size_t)lk.n_bnd * ncol * E, (const void **)&adif));
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl, twostream ? (size_t)lk.n_bnd : 0));
+    if (st.pin_only) return RRTMGP_OK;
     if (chunk) {
         RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
@@ -531,6 +610,36 @@ static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSli
     f.clear_flux_net = s.adv(f.clear_flux_net, nlev); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, nlev);
     o.metric_scaling = s.adv(o.metric_scaling, nlev);
     o.col_offset += (int64_t)s.c0;
+}
+
+static void slice_lw_bcs(rrtmgp_lw_bcs &b, const ColumnSlice &s, size_t nbnd) { b.sfc_emis = s.adv(b.sfc_emis, nbnd); }
+static void slice_sw_bcs(rrtmgp_sw_bcs &b, const ColumnSlice &s, size_t nbnd) {
+    b.cos_zenith = s.adv(b.cos_zenith, 1); b.toa_flux = s.adv(b.toa_flux, 1);
+    b.sfc_alb_direct = s.adv(b.sfc_alb_direct, nbnd); b.sfc_alb_diffuse = s.adv(b.sfc_alb_diffuse, nbnd);
+}
+static void slice_gray(rrtmgp_gray_state &g, const ColumnSlice &s, size_t nc) {
+    const size_t nlay = g.nlay, nlev = nlay + 1;
+    g.ncol = (int64_t)nc;
+    g.lat = s.adv(g.lat, 1); g.t_sfc = s.adv(g.t_sfc, 1);
+    g.p_lay = s.adv(g.p_lay, nlay); g.t_lay = s.adv(g.t_lay, nlay);
+    g.p_lev = s.adv(g.p_lev, nlev); g.t_lev = s.adv(g.t_lev, nlev);
+}
+
+// What a multi-device workspace can shard in one call (include/rrtmgp_hip.h): everything whose slowest dimension is ncol.
+static int check_multi(const rrtmgp_workspace *ws, int state_mem, int bcs_mem, const rrtmgp_flux_out *flux,
+                       const rrtmgp_solve_opts *opts, const void *inc_flux) {
+    if (ws->shards.size() <= 1) return RRTMGP_OK;
+    bool one_device = true;
+    for (auto *s : ws->shards) one_device = one_device && s->device == ws->shards[0]->device;
+    const bool any_dev = state_mem == RRTMGP_MEM_DEVICE || bcs_mem == RRTMGP_MEM_DEVICE || (flux && flux->mem == RRTMGP_MEM_DEVICE) ||
+                         (opts && opts->metric_scaling && opts->metric_mem == RRTMGP_MEM_DEVICE);
+    if (any_dev && !one_device) return set_error(RRTMGP_EINVAL, "a workspace spanning several devices needs host arrays");
+    if (flux && flux->layout != RRTMGP_LAYOUT_NLEV_NCOL)
+        return set_error(RRTMGP_EUNSUPPORTED, "multi-shard solves need the (nlev, ncol) flux layout: ncol must be the slowest dimension");
+    if (flux && (flux->band_flux_up || flux->band_flux_dn || flux->band_flux_net))
+        return set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes cannot be sharded in one call");
+    if (inc_flux) return set_error(RRTMGP_EUNSUPPORTED, "LwBCs.inc_flux (ncol fastest) cannot be sharded in one call");
+    return RRTMGP_OK;
 }
 
 static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, const rrtmgp_flux_out *flux,
@@ -598,10 +707,29 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
     return rc;
 }
 
+// page-lock the caller's WHOLE host arrays (does something on the first call only); `ws` owns the registrations
+template <typename FT>
+static int pin_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+                  int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
+                  const rrtmgp_solve_opts *opts) {
+    Stager pin{ws, {}};
+    pin.pin_only = true;
+    return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+}
+template <typename FT>
+static int pin_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
+                  int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux,
+                  const rrtmgp_solve_opts *opts) {
+    Stager pin{ws, {}};
+    pin.pin_only = true;
+    return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+}
+
 template <typename FT>
 static int solve_lw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(pin_lw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts));
     if (!bcs || bcs->inc_flux || !host_pipeline_applies(as, bcs->mem, flux, opts))
         return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
     return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
@@ -616,6 +744,7 @@ template <typename FT>
 static int solve_sw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    TRY(pin_sw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts));
     if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts))
         return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
     return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
@@ -817,7 +946,8 @@ int rrtmgp_hip_aerosol_lookup_create(const rrtmgp_aerosol_lookup_desc *desc, int
 int rrtmgp_hip_lookup_destroy(rrtmgp_lookup *lk) {
     if (!lk) return RRTMGP_OK;
     (void)hipSetDevice(lk->device);
-    for (void *p : lk->allocs) (void)hipFree(p);
+    for (void *p : lk->allocs) (void)rr_free(p);
+    for (rrtmgp_lookup *r : lk->replicas) rrtmgp_hip_lookup_destroy(r);
     delete lk;
     return RRTMGP_OK;
 }
@@ -848,14 +978,20 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
     if (!ws) return RRTMGP_OK;
     (void)hipSetDevice(ws->device);
     (void)hipStreamSynchronize(ws->stream);
-    for (auto &b : ws->stage) if (b.ptr) (void)hipFree(b.ptr);
-    for (auto &b : ws->stage_alt) if (b.ptr) (void)hipFree(b.ptr);
+    host_unpin_all(ws);
+    if (!ws->shards.empty()) {  // a multi-device head owns its shards and nothing else
+        for (rrtmgp_workspace *s : ws->shards) rrtmgp_hip_workspace_destroy(s);
+        delete ws;
+        return RRTMGP_OK;
+    }
+    for (auto &b : ws->stage) if (b.ptr) (void)rr_free(b.ptr);
+    for (auto &b : ws->stage_alt) if (b.ptr) (void)rr_free(b.ptr);
     for (int i = 0; i < 2; i++) {
         if (ws->ev_in[i]) (void)hipEventDestroy(ws->ev_in[i]);
         if (ws->ev_k[i]) (void)hipEventDestroy(ws->ev_k[i]);
     }
     if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
-    if (ws->scratch.ptr) (void)hipFree(ws->scratch.ptr);
+    if (ws->scratch.ptr) (void)rr_free(ws->scratch.ptr);
     if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);
     if (ws->ev_stop) (void)hipEventDestroy(ws->ev_stop);
     if (ws->own_stream) (void)hipStreamDestroy(ws->own_stream);
@@ -865,12 +1001,15 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
 
 int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream) {
     RR_CHECK(ws, "null workspace");
+    RR_CHECK(ws->shards.empty(), "a multi-device workspace runs each shard on its own stream");
     ws->stream = (hipStream_t)hip_stream;  // NULL is the HIP null (legacy default) stream
     return RRTMGP_OK;
 }
 
 int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws) {
     RR_CHECK(ws, "null workspace");
+    for (rrtmgp_workspace *s : ws->shards) TRY(rrtmgp_hip_workspace_synchronize(s));
+    if (!ws->shards.empty()) return RRTMGP_OK;
     RR_HIP(hipSetDevice(ws->device));
     RR_HIP(hipStreamSynchronize(ws->stream));
     return RRTMGP_OK;
@@ -878,6 +1017,15 @@ int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws) {
 
 int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms) {
     RR_CHECK(ws && ms, "null argument");
+    if (!ws->shards.empty()) {  // the slowest shard
+        *ms = 0;
+        for (rrtmgp_workspace *s : ws->shards) {
+            double m = 0;
+            TRY(rrtmgp_hip_workspace_last_kernel_ms(s, &m));
+            *ms = std::max(*ms, m);
+        }
+        return RRTMGP_OK;
+    }
     RR_HIP(hipSetDevice(ws->device));
     RR_HIP(hipEventSynchronize(ws->ev_stop));
     float f = 0;
@@ -893,37 +1041,147 @@ int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms) {
          : fn<double>(ws, twostream, (lk)->gas64, (cld) ? &(cld)->cld64 : nullptr, (aero) ? &(aero)->aero64 : nullptr, \
                       (lk)->max_int, __VA_ARGS__))
 
+}  // extern "C" (templates need C++ linkage)
+
+// ---- multi-device dispatch of the spectral solvers: slice, pick the replicas, re-enter the single-device entry ----
+static int n_bnd_of(const rrtmgp_workspace *ws, const rrtmgp_lookup *gas) {
+    return ws->ftype == RRTMGP_F32 ? gas->gas32.n_bnd : gas->gas64.n_bnd;
+}
+template <typename BCS, typename SliceBcs, typename Call>
+static int multi_spectral(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, const rrtmgp_lookup *cld, const rrtmgp_lookup *aero,
+                          const rrtmgp_atmos_state *as, const BCS *bcs, const rrtmgp_flux_out *flux,
+                          const rrtmgp_solve_opts *opts, SliceBcs slice_bcs, Call call) {
+    const size_t E = (size_t)ws->ftype, nlev = (size_t)as->nlay + 1;
+    return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+        const ColumnSlice sl{E, c0};
+        rrtmgp_atmos_state a = *as;
+        BCS b = *bcs;
+        rrtmgp_flux_out f = *flux;
+        rrtmgp_solve_opts o{};
+        if (opts) o = *opts; else o.n_gauss_angles = 1;
+        slice_state(a, sl, nc);
+        slice_flux(f, o, sl, nlev);
+        slice_bcs(b, sl);
+        const rrtmgp_lookup *g = lookup_on(gas, sw->device), *c = lookup_on(cld, sw->device), *ae = lookup_on(aero, sw->device);
+        if (!g || (cld && !c) || (aero && !ae))
+            return set_error(RRTMGP_EINVAL, "a lookup has no replica on one of the workspace's devices (use *_lookup_create_multi)");
+        return call(sw, g, c, ae, &a, &b, &f, &o);
+    });
+}
+static int check_multi_spectral(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, const rrtmgp_atmos_state *as, const void *bcs,
+                                int bcs_mem, const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts, const void *inc_flux) {
+    RR_CHECK(ws && gas && as && bcs && flux, "null argument");
+    RR_CHECK(gas->kind == LK_GAS && gas->ftype == ws->ftype, "expected a gas lookup of the workspace's precision");
+    RR_CHECK(as->ncol == ws->ncol && as->nlay == ws->nlay, "state dimensions differ from the workspace");
+    return check_multi(ws, as->mem, bcs_mem, flux, opts, inc_flux);
+}
+static const rrtmgp_lookup *head_replica(const rrtmgp_workspace *ws, const rrtmgp_lookup *lk) {
+    return lk ? lookup_on(lk, ws->shards[0]->device) : nullptr;
+}
+
+extern "C" {
+
 int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
                                     const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                                     const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     const int twostream = 1;
+    if (ws && !ws->shards.empty()) {
+        TRY(check_multi_spectral(ws, lookup_lw, as, bcs, bcs ? bcs->mem : 0, flux, opts, bcs ? bcs->inc_flux : nullptr));
+        const rrtmgp_lookup *g = head_replica(ws, lookup_lw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
+        RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
+        const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
+        return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
+                              [nb](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb); },
+                              rrtmgp_hip_rte_lw_2stream_solve);
+    }
+    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     return GAS_DISPATCH(ws, solve_lw_host, lookup_lw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_lw, const rrtmgp_lookup *cld,
                                    const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                                    const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     const int twostream = 0;
+    if (ws && !ws->shards.empty()) {
+        TRY(check_multi_spectral(ws, lookup_lw, as, bcs, bcs ? bcs->mem : 0, flux, opts, bcs ? bcs->inc_flux : nullptr));
+        const rrtmgp_lookup *g = head_replica(ws, lookup_lw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
+        RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
+        const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
+        return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
+                              [nb](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb); },
+                              rrtmgp_hip_rte_lw_noscat_solve);
+    }
+    TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
     return GAS_DISPATCH(ws, solve_lw_host, lookup_lw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_lookup *cld,
                                     const rrtmgp_lookup *aero, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
                                     const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(check_common(ws, lookup_sw, 1, cld, aero, as));
     const int twostream = 1;
+    if (ws && !ws->shards.empty()) {
+        TRY(check_multi_spectral(ws, lookup_sw, as, bcs, bcs ? bcs->mem : 0, flux, opts, nullptr));
+        const rrtmgp_lookup *g = head_replica(ws, lookup_sw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
+        RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        TRY(GAS_DISPATCH(ws, pin_sw, g, c, ae, as, bcs, flux, opts));
+        const size_t nb = (size_t)n_bnd_of(ws, lookup_sw);
+        return multi_spectral(ws, lookup_sw, cld, aero, as, bcs, flux, opts,
+                              [nb](rrtmgp_sw_bcs &b, const ColumnSlice &sl) { slice_sw_bcs(b, sl, nb); },
+                              rrtmgp_hip_rte_sw_2stream_solve);
+    }
+    TRY(check_common(ws, lookup_sw, 1, cld, aero, as));
     return GAS_DISPATCH(ws, solve_sw_host, lookup_sw, cld, aero, as, bcs, flux, opts);
 }
 
 int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lookup_sw, const rrtmgp_atmos_state *as,
                                    const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(check_common(ws, lookup_sw, 1, nullptr, nullptr, as));
     const int twostream = 0;
     const rrtmgp_lookup *cld = nullptr, *aero = nullptr;
+    if (ws && !ws->shards.empty()) {
+        TRY(check_multi_spectral(ws, lookup_sw, as, bcs, bcs ? bcs->mem : 0, flux, opts, nullptr));
+        const rrtmgp_lookup *g = head_replica(ws, lookup_sw);
+        RR_CHECK(g, "the lookup has no replica on the workspace's first device");
+        TRY(GAS_DISPATCH(ws, pin_sw, g, cld, aero, as, bcs, flux, opts));
+        const size_t nb = (size_t)n_bnd_of(ws, lookup_sw);
+        return multi_spectral(ws, lookup_sw, cld, aero, as, bcs, flux, opts,
+                              [nb](rrtmgp_sw_bcs &b, const ColumnSlice &sl) { slice_sw_bcs(b, sl, nb); },
+                              [](rrtmgp_workspace *sw, const rrtmgp_lookup *g2, const rrtmgp_lookup *, const rrtmgp_lookup *,
+                                 const rrtmgp_atmos_state *a, const rrtmgp_sw_bcs *b, const rrtmgp_flux_out *f,
+                                 const rrtmgp_solve_opts *o) { return rrtmgp_hip_rte_sw_noscat_solve(sw, g2, a, b, f, o); });
+    }
+    TRY(check_common(ws, lookup_sw, 1, nullptr, nullptr, as));
     return GAS_DISPATCH(ws, solve_sw_host, lookup_sw, cld, aero, as, bcs, flux, opts);
 }
+
+}  // extern "C"
+
+// gray solves / preparation steps on a multi-device workspace: same slicing, no lookups
+template <typename BCS, typename SliceBcs, typename Call>
+static int multi_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const BCS *bcs, const rrtmgp_flux_out *flux,
+                      const rrtmgp_solve_opts *opts, SliceBcs slice_bcs, Call call) {
+    RR_CHECK(gs && bcs && flux, "null argument");
+    RR_CHECK(gs->ncol == ws->ncol && gs->nlay == ws->nlay, "state dimensions differ from the workspace");
+    TRY(check_multi(ws, gs->mem, bcs->mem, flux, opts, nullptr));
+    const size_t E = (size_t)ws->ftype, nlev = (size_t)gs->nlay + 1;
+    return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+        const ColumnSlice sl{E, c0};
+        rrtmgp_gray_state g = *gs;
+        BCS b = *bcs;
+        rrtmgp_flux_out f = *flux;
+        rrtmgp_solve_opts o{};
+        if (opts) o = *opts; else o.n_gauss_angles = 1;
+        slice_gray(g, sl, nc);
+        slice_flux(f, o, sl, nlev);
+        slice_bcs(b, sl);
+        return call(sw, &g, &b, &f, &o);
+    });
+}
+static void slice_gray_lw_bcs(rrtmgp_lw_bcs &b, const ColumnSlice &sl) { b.sfc_emis = sl.adv(b.sfc_emis, 1); b.inc_flux = sl.adv(b.inc_flux, 1); }
+static void slice_gray_sw_bcs(rrtmgp_sw_bcs &b, const ColumnSlice &sl) { slice_sw_bcs(b, sl, 1); }
+
+extern "C" {
 
 static int check_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const void *bcs, const rrtmgp_flux_out *flux) {
     RR_CHECK(ws && gs && bcs && flux, "null argument");
@@ -936,6 +1194,7 @@ static int check_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const v
 
 int rrtmgp_hip_rte_lw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_lw_bcs *bcs,
                                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (ws && !ws->shards.empty()) return multi_gray(ws, as, bcs, flux, opts, slice_gray_lw_bcs, rrtmgp_hip_rte_lw_2stream_solve_gray);
     TRY(check_gray(ws, as, bcs, flux));
     RR_CHECK(as->lat && as->t_lay && as->t_lev && as->t_sfc && bcs->sfc_emis, "gray LW: missing array");
     return ws->ftype == RRTMGP_F32 ? solve_gray_lw_t<float>(ws, 1, as, bcs, flux, opts)
@@ -943,6 +1202,7 @@ int rrtmgp_hip_rte_lw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray
 }
 int rrtmgp_hip_rte_lw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_lw_bcs *bcs,
                                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (ws && !ws->shards.empty()) return multi_gray(ws, as, bcs, flux, opts, slice_gray_lw_bcs, rrtmgp_hip_rte_lw_noscat_solve_gray);
     TRY(check_gray(ws, as, bcs, flux));
     RR_CHECK(as->lat && as->t_lay && as->t_lev && as->t_sfc && bcs->sfc_emis, "gray LW: missing array");
     RR_CHECK(!opts || opts->n_gauss_angles <= 1, "gray radiation is solved with a single quadrature angle");
@@ -951,6 +1211,7 @@ int rrtmgp_hip_rte_lw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_
 }
 int rrtmgp_hip_rte_sw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_sw_bcs *bcs,
                                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (ws && !ws->shards.empty()) return multi_gray(ws, as, bcs, flux, opts, slice_gray_sw_bcs, rrtmgp_hip_rte_sw_2stream_solve_gray);
     TRY(check_gray(ws, as, bcs, flux));
     RR_CHECK(bcs->cos_zenith && bcs->toa_flux && bcs->sfc_alb_direct && bcs->sfc_alb_diffuse && flux->flux_dn_dir,
              "gray SW: missing array");
@@ -959,6 +1220,7 @@ int rrtmgp_hip_rte_sw_2stream_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray
 }
 int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as, const rrtmgp_sw_bcs *bcs,
                                         const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
+    if (ws && !ws->shards.empty()) return multi_gray(ws, as, bcs, flux, opts, slice_gray_sw_bcs, rrtmgp_hip_rte_sw_noscat_solve_gray);
     TRY(check_gray(ws, as, bcs, flux));
     RR_CHECK(bcs->cos_zenith && bcs->toa_flux && flux->flux_dn_dir, "gray SW: missing array");
     return ws->ftype == RRTMGP_F32 ? solve_gray_sw_t<float>(ws, 0, as, bcs, flux, opts)
@@ -968,6 +1230,14 @@ int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_
 int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry,
                                const rrtmgp_params *params, const void *vmr_h2o, const void *lat) {
     RR_CHECK(ws && p_lev && col_dry && params, "null argument");
+    if (!ws->shards.empty()) {
+        const size_t nlay = (size_t)ws->nlay;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
+            const ColumnSlice sl{(size_t)ws->ftype, c0};
+            return rrtmgp_hip_compute_col_gas(sw, mem, sl.adv(p_lev, nlay + 1), sl.adv(col_dry, nlay), params,
+                                              sl.adv(vmr_h2o, nlay), sl.adv(lat, 1));
+        });
+    }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? col_gas_t<float>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat)
                                    : col_gas_t<double>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat);
@@ -976,6 +1246,14 @@ int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_
 int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
                                          const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o) {
     RR_CHECK(ws && rh && p_lay && t_lay && params && vmr_h2o, "null argument");
+    if (!ws->shards.empty()) {
+        const size_t nlay = (size_t)ws->nlay;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
+            const ColumnSlice sl{(size_t)ws->ftype, c0};
+            return rrtmgp_hip_compute_relative_humidity(sw, mem, sl.adv(rh, nlay), sl.adv(p_lay, nlay), sl.adv(t_lay, nlay),
+                                                        params, sl.adv(vmr_h2o, nlay));
+        });
+    }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? rel_hum_t<float>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o)
                                    : rel_hum_t<double>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o);
@@ -985,6 +1263,18 @@ int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state
                                   const rrtmgp_prepare_opts *opts) {
     RR_CHECK(ws && as && params && opts, "null argument");
     RR_CHECK(as->ncol >= 0 && as->ncol <= ws->ncol && as->nlay == ws->nlay, "state does not fit the workspace");
+    if (!ws->shards.empty()) {
+        RR_CHECK(as->ncol == ws->ncol, "state dimensions differ from the workspace");
+        const size_t nlay = (size_t)as->nlay;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const ColumnSlice sl{(size_t)ws->ftype, c0};
+            rrtmgp_atmos_state a = *as;
+            rrtmgp_prepare_opts o = *opts;
+            slice_state(a, sl, nc);
+            o.center_z = sl.adv(o.center_z, nlay); o.face_z = sl.adv(o.face_z, nlay + 1);
+            return rrtmgp_hip_prepare_atmosphere(sw, &a, params, &o);
+        });
+    }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? prepare_t<float>(ws, as, params, opts) : prepare_t<double>(ws, as, params, opts);
 }
@@ -993,9 +1283,28 @@ int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_s
                                        const rrtmgp_prepare_opts *opts) {
     RR_CHECK(ws && as && params && opts, "null argument");
     RR_CHECK(as->ncol >= 0 && as->ncol <= ws->ncol && as->nlay == ws->nlay, "state does not fit the workspace");
+    if (!ws->shards.empty()) {
+        RR_CHECK(as->ncol == ws->ncol, "state dimensions differ from the workspace");
+        const size_t nlay = (size_t)as->nlay;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const ColumnSlice sl{(size_t)ws->ftype, c0};
+            rrtmgp_gray_state g = *as;
+            rrtmgp_prepare_opts o = *opts;
+            slice_gray(g, sl, nc);
+            o.center_z = sl.adv(o.center_z, nlay); o.face_z = sl.adv(o.face_z, nlay + 1);
+            return rrtmgp_hip_prepare_atmosphere_gray(sw, &g, params, &o);
+        });
+    }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? prepare_gray_t<float>(ws, as, params, opts)
                                    : prepare_gray_t<double>(ws, as, params, opts);
+}
+
+int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, int64_t *host_registrations) {
+    if (device_allocs) *device_allocs = g_dev_allocs.load();
+    if (device_frees) *device_frees = g_dev_frees.load();
+    if (host_registrations) *host_registrations = g_host_regs.load();
+    return RRTMGP_OK;
 }
 
 double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32_t is_sw, int32_t draw) {

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <map>
 #include <utility>
@@ -29,7 +30,7 @@ struct DevGas {
     // every global_load of the hot loop); offsets in bytes:
     const char *arena;
     unsigned off_kmajor;     // SW: [t][p][eta][gpt]; LW: [t][p][eta][gpt][2] = (kmajor, planck_fraction) pairs
-    unsigned off_kminor[2];  // [t][eta][contrib], contrib = koff[b] + i*ng_b + (g - lo_b); region 0 lower, 1 upper
+    unsigned off_kminor[2];  // [t][eta][contrib], contrib = koff[b] + ((i/4)*ng_b + (g - lo_b))*4 + i%4; region 0 lower, 1 upper
     unsigned off_rayl[2];    // [t][eta][gpt]   (SW)
     const FT *t_planck;    // [n_t_plnk]                  (LW)
     const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
@@ -43,9 +44,12 @@ struct DevGas {
     // minor gases, region 0 = lower, 1 = upper atmosphere
     const int *m_bnd_st[2];   // [n_bnd+1] 0-based start into gasdata columns
     const int *m_gasdata[2];  // (4, n_min_absrb)
-    const int *m_koff[2];     // [n_bnd] offset of the band's block along the contributor axis
-    int m_ncontrib[2];
+    const int *m_koff[2];     // [n_bnd] offset of the band's block along the (padded) contributor axis
+    const int *m_st4[2];      // [n_bnd] first scaling slot of the band (a multiple of MINOR_GROUP)
+    const int *m_slot_int[2]; // [m_nslot] gasdata column of each scaling slot, -1 for padding
+    int m_ncontrib[2];        // row length of kminor: padded contributors per (t, eta)
     int m_nint[2];            // minor intervals (gasdata columns) per region
+    int m_nslot[2];           // scaling slots per region (every band padded to whole groups)
     const FT *solar_src_scaled;  // [n_gpt]         (SW)
 };
 
@@ -97,6 +101,8 @@ struct DeviceBuffer {
 
 enum LookupKind { LK_GAS = 1, LK_CLOUD = 2, LK_AEROSOL = 3 };
 
+constexpr int MINOR_GROUP = 4;  // minor-gas contributors fetched by one load per interpolation corner
+
 }  // namespace rrtmgp
 
 struct rrtmgp_lookup {
@@ -112,7 +118,9 @@ struct rrtmgp_lookup {
     rrtmgp::DevAero<float> aero32;
     rrtmgp::DevAero<double> aero64;
     int max_minor;  // largest per-band minor count (either region)
-    int max_int;    // largest minor-interval count of either region
+    int max_int;    // scaling slots of the larger region (m_nslot)
+    // *_lookup_create_multi: replicas on the other devices (owned by this head; each has no replicas of its own)
+    std::vector<rrtmgp_lookup *> replicas;
 };
 
 struct rrtmgp_workspace {
@@ -133,6 +141,10 @@ struct rrtmgp_workspace {
     rrtmgp::DeviceBuffer scratch;
     // resident workgroups per CU of each (kernel, dynamic LDS size) launched so far
     std::map<std::pair<const void *, size_t>, int> occupancy;
+    // workspace_create_multi: one single-device workspace per shard (owned by this head, which holds no device
+    // resources of its own); shard s covers the global columns [shard_c0[s], shard_c0[s + 1])
+    std::vector<rrtmgp_workspace *> shards;
+    std::vector<int64_t> shard_c0;
 };
 
 namespace rrtmgp {
@@ -154,6 +166,21 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // ensure ws->stage[slot] holds at least `bytes`
 int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes);
 int scratch_ensure(rrtmgp_workspace *ws, size_t bytes);
+
+// every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
+hipError_t rr_malloc(void **p, size_t bytes);
+hipError_t rr_free(void *p);
+// page-lock a caller's host array once (process-wide registry, owner = ws); false = it stays pageable
+bool host_pin(rrtmgp_workspace *ws, const void *p, size_t bytes);
+void host_unpin_all(rrtmgp_workspace *ws);
+
+// the replica of `lk` that lives on `device` (lk itself when it does), or nullptr
+const rrtmgp_lookup *lookup_on(const rrtmgp_lookup *lk, int device);
+const std::string &last_error_string();
+
+// Runs `shard_call(shard_workspace, first_column, n_columns)` for every shard of a multi-device workspace,
+// concurrently (one host thread per shard), and returns the first failure (message preserved).
+int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, size_t, size_t)> &shard_call);
 
 // Launchers implemented in the .hip translation units.  `which`: 1 = two-stream, 0 = no-scattering.
 template <typename FT>

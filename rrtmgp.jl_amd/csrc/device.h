@@ -245,11 +245,11 @@ __device__ __forceinline__ void wave_sum16(const FT (&v)[16], FT (&w)[4]) {
 struct ColDims {
     int nlay, nlev, ngas1 /* rows of the gas table */, nwaves, nbnd;
     int lw, twostream, has_cld, has_aero, n_acc /* accumulated flux components per level */;
-    int max_int; /* largest minor-interval count of either region */
+    int max_int; /* minor-gas scaling slots per layer row (the larger region's; a multiple of MINOR_GROUP) */
     int nseg;    /* flux accumulator segments per block: nwaves, or 4 per wave with per-band fluxes */
     int diag;    /* clear-sky fluxes are carried next to the all-sky ones (n_acc doubles) */
     /* sizes of the small lookup tables mirrored in LDS (TabCache) */
-    int n_t_ref, n_p_ref, n_t_plnk, n_gases_ref, nint0, nint1;
+    int n_t_ref, n_p_ref, n_t_plnk, n_gases_ref, nint0, nint1, nslot0, nslot1;
 };
 
 // 4 values read with one ds_read_b128 (Float32) / two (Float64)
@@ -285,10 +285,12 @@ template <typename FT>
 struct alignas(32) ChunkFixed {
     V4<FT> eta[CH * NBMAX];  // fe1, fe2, cm1, cm2
     V4<FT> cld[CH * NBMAX];  // cloud (tau, tau*ssa, tau*ssa*g, -) or (absorption tau, -, -, -)
-    V4<FT> aer[CH * NBMAX];
     FT Blev[(CH + 1) * NBMAX];
     int je[CH * NBMAX];      // je1 | je2 << 8
-    FT Blay[CH * NBMAX];     // layer Planck sources: no-scattering LW only; last, so the other solvers do not allocate it
+    FT pad[NBMAX];           // keeps the tail 32-byte aligned
+    // the tail is only allocated as far as it is used (carve_shared):
+    FT Blay[CH * NBMAX];     // layer Planck sources: no-scattering LW only
+    V4<FT> aer[CH * NBMAX];  // aerosol (tau, tau*ssa, tau*ssa*g, -): only with an aerosol lookup
 };
 
 template <typename FT>
@@ -297,7 +299,8 @@ struct ColShared {
     LayerRec<FT> *lay;   // constant offset
     LevelRec<FT> *lev;   // [nlev]
     FT *vmr;             // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
-    FT *mscale;          // [max_int][CH] minor-gas scalings of the current chunk
+    int mscale_row;      // = max_int
+    FT *mscale;          // [CH][max_int] minor-gas scalings of the current chunk, slot-contiguous per layer (16-byte groups)
     FT *acc;             // [nseg][nlev][n_acc]
     int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
     FT *miscf;           // [0]: pl_sfc_f
@@ -305,7 +308,7 @@ struct ColShared {
     // workgroup (not per column) so that those dependent reads are LDS round trips instead of L2 ones
     FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_vmr_ref;
     FT *tab_vmr_gm;  // VmrGM: the well-mixed vector, [ngas1] with entry 0 = 1 (it does not depend on the column)
-    int *tab_key_species, *tab_gasdata[2];
+    int *tab_key_species, *tab_gasdata[2], *tab_slot_int[2];
 };
 
 template <typename T>
@@ -319,11 +322,16 @@ template <typename FT>
 __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
     char *p = base;
     s.ch = carve<ChunkFixed<FT>>(p, 1);
-    if (!(d.lw && !d.twostream)) p -= sizeof(FT) * CH * NBMAX;  // Blay (a multiple of 32 bytes)
+    // drop the unused tail of the chunk record: aer, and Blay when neither is needed (both multiples of 32 bytes)
+    if (!d.has_aero) {
+        p -= sizeof(V4<FT>) * CH * NBMAX;
+        if (!(d.lw && !d.twostream)) p -= sizeof(FT) * CH * NBMAX;
+    }
     s.lay = carve<LayerRec<FT>>(p, d.nlay);
     s.lev = carve<LevelRec<FT>>(p, d.nlev);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
-    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : 1) * CH);
+    s.mscale_row = d.max_int;
+    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_GROUP) * CH);
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
@@ -335,6 +343,8 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
     s.tab_key_species = carve<int>(p, 4 * d.nbnd);
     s.tab_gasdata[0] = carve<int>(p, 4 * (d.nint0 > 0 ? d.nint0 : 1));
     s.tab_gasdata[1] = carve<int>(p, 4 * (d.nint1 > 0 ? d.nint1 : 1));
+    s.tab_slot_int[0] = carve<int>(p, d.nslot0 > 0 ? d.nslot0 : 1);
+    s.tab_slot_int[1] = carve<int>(p, d.nslot1 > 0 ? d.nslot1 : 1);
     return (size_t)(p - base);
 }
 
@@ -352,11 +362,14 @@ __device__ inline DevGas<FT> cache_small_tables(const ColShared<FT> &sh, const C
     for (int i = tid; i < 4 * d.nbnd; i += nt) sh.tab_key_species[i] = lk.key_species[i];
     for (int i = tid; i < 4 * d.nint0; i += nt) sh.tab_gasdata[0][i] = lk.m_gasdata[0][i];
     for (int i = tid; i < 4 * d.nint1; i += nt) sh.tab_gasdata[1][i] = lk.m_gasdata[1][i];
+    for (int i = tid; i < d.nslot0; i += nt) sh.tab_slot_int[0][i] = lk.m_slot_int[0][i];
+    for (int i = tid; i < d.nslot1; i += nt) sh.tab_slot_int[1][i] = lk.m_slot_int[1][i];
     DevGas<FT> v = lk;
     v.t_ref = sh.tab_t_ref; v.ln_p_ref = sh.tab_ln_p_ref; v.vmr_ref = sh.tab_vmr_ref;
     if (d.lw) v.t_planck = sh.tab_t_planck;
     v.key_species = sh.tab_key_species;
     v.m_gasdata[0] = sh.tab_gasdata[0]; v.m_gasdata[1] = sh.tab_gasdata[1];
+    v.m_slot_int[0] = sh.tab_slot_int[0]; v.m_slot_int[1] = sh.tab_slot_int[1];
     __syncthreads();
     return v;
 }
@@ -635,7 +648,13 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
     const int nlay = d.nlay, nb = d.nbnd, tid = threadIdx.x, nt = blockDim.x;
     const int NE = lk.n_eta;
     for (int u = tid; u < CH * nb; u += nt) {
+#ifdef RR_PREP_KK_MINOR
         const int b = u / CH, kk = u % CH, k = k0 + kk;  // CH is a power of two
+#else
+        // consecutive lanes take consecutive bands of one layer: the record stores below are contiguous in LDS
+        // (16-byte stride between lanes instead of 256) and the sh.lay[k] / sh.lev[k] reads are broadcasts
+        const int kk = u / nb, b = u - kk * nb, k = k0 + kk;
+#endif
         if (kk >= kn) continue;
         const int t = kk * NBMAX + b;
         // Planck band sources at levels k0 .. k0 + kn (interp1d_equispaced, compute_optical_props.jl:180-186): the
@@ -721,13 +740,16 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
             sh.ch->aer[t] = V4<FT>{a0, a1, a2, FT(0)};
         }
     }
-    // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0)
-    for (int t = tid; t < d.max_int * CH; t += nt) {
-        const int i = t / CH, kk = t % CH, k = k0 + kk;
+    // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0) and in the
+    // padding slots.  Row kk holds the slots of layer k0 + kk: consecutive lanes write consecutive words.
+    const int S = d.max_int;
+    for (int t = tid; t < S * CH; t += nt) {
+        const int kk = t / S, slot = t - kk * S, k = k0 + kk;
         if (kk >= kn) continue;
         const int tropo = sh.lay[k].idx >> 16;
         FT scaling = FT(0);
-        if (i < (tropo ? lk.m_nint[1] : lk.m_nint[0])) {
+        const int i = slot < (tropo ? lk.m_nslot[1] : lk.m_nslot[0]) ? (tropo ? lk.m_slot_int[1] : lk.m_slot_int[0])[slot] : -1;
+        if (i >= 0) {
             const int *gd = (tropo ? lk.m_gasdata[1] : lk.m_gasdata[0]) + 4 * i;
             const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
             if (vmr_imnr > FT(0)) {
@@ -742,7 +764,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
                 }
             }
         }
-        sh.mscale[i * CH + kk] = scaling;
+        sh.mscale[t] = scaling;
     }
 }
 
@@ -750,11 +772,11 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
 // (explicit lower/upper members: arrays indexed by the run-time region would live in scratch memory)
 struct LaneBand {
     int g, ibnd, ngb;
-    int m_pack;          // st0 | n0 << 8 | st1 << 16 | n1 << 24   (minor-interval start / count per region)
+    int m_pack;          // g0 | n0 << 8 | g1 << 16 | n1 << 24   (first scaling GROUP of the band / contributor count, per region)
     unsigned gk;         // arena byte offset of this lane's g-point in the kmajor table
-    unsigned gm0, gm1;   // ... of this lane's first contributor in kminor lower / upper
+    unsigned gm0, gm1;   // ... of this lane's first contributor group in kminor lower / upper
     unsigned gE;         // g * sizeof(FT)
-    __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }
+    __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }  // first group
     __device__ __forceinline__ int m_n(unsigned tropo) const { return (m_pack >> (tropo ? 24 : 8)) & 0xff; }
     __device__ __forceinline__ unsigned gm(unsigned tropo) const { return tropo ? gm1 : gm0; }
 };
@@ -766,14 +788,14 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     lb.ibnd = lk.gpt2bnd[g];
     const int gi = g - lk.bnd_lo[lb.ibnd];
     lb.ngb = lk.bnd_ng[lb.ibnd];
-    const int st0 = lk.m_bnd_st[0][lb.ibnd], st1 = lk.m_bnd_st[1][lb.ibnd];
-    const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - st0, n1 = lk.m_bnd_st[1][lb.ibnd + 1] - st1;
-    lb.m_pack = st0 | (n0 << 8) | (st1 << 16) | (n1 << 24);
+    const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - lk.m_bnd_st[0][lb.ibnd], n1 = lk.m_bnd_st[1][lb.ibnd + 1] - lk.m_bnd_st[1][lb.ibnd];
+    const int g0 = lk.m_st4[0][lb.ibnd] / MINOR_GROUP, g1 = lk.m_st4[1][lb.ibnd] / MINOR_GROUP;
+    lb.m_pack = g0 | (n0 << 8) | (g1 << 16) | (n1 << 24);
     constexpr unsigned E = sizeof(FT);
     lb.gE = g * E;
     lb.gk = lk.off_kmajor + g * (lk.is_sw ? E : 2 * E);
-    lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi) * E;
-    lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi) * E;
+    lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi * MINOR_GROUP) * E;
+    lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi * MINOR_GROUP) * E;
     return lb;
 }
 
@@ -826,53 +848,46 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
     }
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
-    // The first MG intervals are loaded UNCONDITIONALLY, right behind the kmajor corners and before
-    // anything is consumed: one exposed latency per layer, no divergent branch around the common case.
-    // Slots past n re-read interval n-1, a band without minor gases reads the start of the arena
-    // (padded by build_gas); both carry a zero scaling, which leaves the (in-order) sum unchanged.
+    // The contributors of a g-point sit in groups of MINOR_GROUP = 4 (build_gas): one 16-byte load per
+    // interpolation corner and one 16-byte LDS read of the 4 scalings serve a whole group.  The first group is
+    // loaded UNCONDITIONALLY, right behind the kmajor corners and before anything is consumed: one exposed
+    // latency per layer, no exec masking.  Padding entries (a band without minor gases owns one all-padding group)
+    // are 0 in the table and carry a zero scaling, which leaves the in-order sum unchanged.
     FT tau_minor = FT(0);
+#ifdef RR_EXP_NO_MINOR  // timing-only experiment: no minor-gas gathers
+    const int n = 0;
+#else
     const int n = lb.m_n(tropo);
-    constexpr int MG = 3;
+#endif
     const char *kmn = lk.arena;
     const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
-    const unsigned a1 = n > 0 ? __umul24(jT * NE + je1, NCb) + lb.gm(tropo) : lb.gE;
-    const unsigned a2 = n > 0 ? __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo) : lb.gE;
-    const unsigned cstep = lb.ngb * E;
-    const FT *ms = sh.mscale + lb.m_st(tropo) * CH + kk;
+    const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
+    const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
+    const unsigned gstep = lb.ngb * (MINOR_GROUP * E);  // byte distance between the groups of one g-point
+    const FT *ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_GROUP;
     const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
-    {
-        FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
-#pragma unroll
-        for (int j = 0; j < MG; j++) {
-            const int i = j < n ? j : (n > 0 ? n - 1 : 0);
-            const unsigned c = __umul24((unsigned)i, cstep);
-            const unsigned x1 = a1 + c, x2 = a2 + c;
-            c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
-            c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
-            sc[j] = j < n ? ms[i * CH] : FT(0);
-        }
+    auto minor_group = [&](unsigned x1, unsigned x2, const FT *sc4, bool wait) {
+        const V4<FT> c11 = ldg<V4<FT>>(kmn, x1), c21 = ldg<V4<FT>>(kmn + NCb, x1);
+        const V4<FT> c12 = ldg<V4<FT>>(kmn, x2), c22 = ldg<V4<FT>>(kmn + NCb, x2);
+        const V4<FT> sc = *reinterpret_cast<const V4<FT> *>(sc4);
 #ifndef RR_NO_GATHER_WAIT
         // every gather of this layer has been issued: one wait instead of one per operand
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+        if (wait) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
 #endif
-#pragma unroll
-        for (int j = 0; j < MG; j++)  // interp2d, optics_utils.jl:85-98
-            tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
-    }
-    for (int i0 = MG; i0 < n; i0 += MG) {  // further groups (bands with more than MG minor gases)
-        FT c11[MG], c21[MG], c12[MG], c22[MG], sc[MG];
-#pragma unroll
-        for (int j = 0; j < MG; j++) {
-            const int i = (i0 + j < n) ? i0 + j : n - 1;
-            const unsigned c = __umul24((unsigned)i, cstep);
-            const unsigned x1 = a1 + c, x2 = a2 + c;
-            c11[j] = ldg<FT>(kmn, x1); c21[j] = ldg<FT>(kmn + NCb, x1);
-            c12[j] = ldg<FT>(kmn, x2); c22[j] = ldg<FT>(kmn + NCb, x2);
-            sc[j] = (i0 + j < n) ? ms[i * CH] : FT(0);
-        }
-#pragma unroll
-        for (int j = 0; j < MG; j++)
-            tau_minor += (w11 * c11[j] + w21 * c21[j] + w12 * c12[j] + w22 * c22[j]) * sc[j];
+        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order
+        tau_minor += (w11 * c11.x + w21 * c21.x + w12 * c12.x + w22 * c22.x) * sc.x;
+        tau_minor += (w11 * c11.y + w21 * c21.y + w12 * c12.y + w22 * c22.y) * sc.y;
+        tau_minor += (w11 * c11.z + w21 * c21.z + w12 * c12.z + w22 * c22.z) * sc.z;
+        tau_minor += (w11 * c11.w + w21 * c21.w + w12 * c12.w + w22 * c22.w) * sc.w;
+    };
+#ifndef RR_EXP_NO_MINOR
+    minor_group(a1, a2, ms, true);
+#else
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    for (int i0 = MINOR_GROUP; i0 < n; i0 += MINOR_GROUP) {  // further groups (bands with more than 4 minor gases)
+        const unsigned c = __umul24((unsigned)(i0 / MINOR_GROUP), gstep);
+        minor_group(a1 + c, a2 + c, ms + i0, false);
     }
     const FT tau_major = (cm1 * (omfP * (omfT * (omfe1 * k000 + fe1 * k100)) + fP * (omfT * (omfe1 * k010 + fe1 * k110))) +
                           cm2 * (omfP * (fT * (omfe2 * q000 + fe2 * q100)) + fP * (fT * (omfe2 * q010 + fe2 * q110)))) *
@@ -938,8 +953,25 @@ struct Sweep {
     char *base;     // this workgroup's slab (wave-uniform)
     unsigned lane;  // threadIdx.x * sizeof(FT)
     unsigned row;   // blockDim.x * sizeof(FT)
-    __device__ __forceinline__ FT &at(int lev, int a) const {
-        return *reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
+    __device__ __forceinline__ FT *ptr(int lev, int a) const {
+#ifdef RR_EXP_SCRATCH_ROW0  // timing-only experiment: every access hits level 0's rows (same instructions, 1/nlev of the footprint)
+        lev = 0;
+#endif
+        return reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
+    }
+    __device__ __forceinline__ void put(int lev, int a, FT v) const {
+#ifdef RR_SCRATCH_NT_STORE
+        __builtin_nontemporal_store(v, ptr(lev, a));
+#else
+        *ptr(lev, a) = v;
+#endif
+    }
+    __device__ __forceinline__ FT get(int lev, int a) const {
+#ifdef RR_SCRATCH_NT_LOAD
+        return __builtin_nontemporal_load(ptr(lev, a));
+#else
+        return *ptr(lev, a);
+#endif
     }
 };
 

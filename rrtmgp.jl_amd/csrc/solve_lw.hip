@@ -166,11 +166,13 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             // one adding step for one of the two streams: voff / aoff = its slots in the sweep record / accumulators
             auto adding = [&](FT &alb, FT &sr, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff) {
                 const FT denom = m_rcp(FT(1) - Rdif * alb);  // Eq 10
-                sw.at(kl, voff) = Tdif * denom;                        // A
-                sw.at(kl, voff + 1) = (Rdif * sr + src_dn) * denom;    // B
-                sw.at(kl, voff + 2) = alb;
+                sw.put(kl, voff, Tdif * denom);                        // A
+                sw.put(kl, voff + 1, (Rdif * sr + src_dn) * denom);    // B
+                sw.put(kl, voff + 2, alb);
+#ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 const FT ss = seg_sum<BAND>(sr * amask);
                 if (writer) acc[kl * NA + aoff] = ss;
+#endif
                 const FT alb_n = Rdif + Tdif * Tdif * alb * denom;  // Eq 9
                 sr = src_up + Tdif * denom * (sr + alb * src_dn);   // Eq 11
                 alb = alb_n;
@@ -188,6 +190,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
+#ifdef RR_EXP_PREP_ONCE  // timing-only experiment: chunk records prepared for the first chunk only (barriers kept)
+                if (c == 0)
+#endif
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
                 __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
@@ -242,8 +247,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
 #pragma unroll
                 for (int j = 0; j < DBT; j++) {
                     const int k = kh - j >= 0 ? kh - j : 0;
-                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); AL[j] = sw.at(k, 2);
-                    if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); ALc[j] = sw.at(k, 5); }
+                    A[j] = sw.get(k, 0); B[j] = sw.get(k, 1); AL[j] = sw.get(k, 2);
+                    if (DIAG) { Ac[j] = sw.get(k, 3); Bc[j] = sw.get(k, 4); ALc[j] = sw.get(k, 5); }
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
@@ -332,13 +337,13 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     } else {
                         lev_src = m_sqrt_pos(inc_prev * lev_src_dec);
                     }
-                    sw.at(k, 0) = tau;
-                    sw.at(k, 1) = lay_src;
-                    sw.at(k, 2) = lev_src;
+                    sw.put(k, 0, tau);
+                    sw.put(k, 1, lay_src);
+                    sw.put(k, 2, lev_src);
                     inc_prev = lev_src_inc;
                 }
             }
-            sw.at(nlay, 2) = inc_prev;
+            sw.put(nlay, 2, inc_prev);
             const FT tthresh = tau_thresh<FT>();
             for (int imu = 0; imu < a.n_angles; imu++) {
                 const FT Ds = a.Ds[imu], w_mu = a.wts[imu];
@@ -350,9 +355,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     if (writer) acc[nlay * 2 + 1] = first ? sd : acc[nlay * 2 + 1] + sd;
                 }
                 for (int k = nlay - 1; k >= 0; k--) {
-                    const FT tau_loc = sw.at(k, 0) * Ds;
+                    const FT tau_loc = sw.get(k, 0) * Ds;
                     const FT trans = m_exp(-tau_loc);
-                    const FT lay_src = sw.at(k, 1), lev_src = sw.at(k, 2);
+                    const FT lay_src = sw.get(k, 1), lev_src = sw.get(k, 2);
                     const FT fact = (tau_loc > tthresh)
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
@@ -366,9 +371,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     if (writer) acc[0] = first ? su : acc[0] + su;
                 }
                 for (int lev = 1; lev <= nlay; lev++) {
-                    const FT tau_loc = sw.at(lev - 1, 0) * Ds;
+                    const FT tau_loc = sw.get(lev - 1, 0) * Ds;
                     const FT trans = m_exp(-tau_loc);
-                    const FT lay_src = sw.at(lev - 1, 1), lev_src = sw.at(lev, 2);
+                    const FT lay_src = sw.get(lev - 1, 1), lev_src = sw.get(lev, 2);
                     const FT fact = (tau_loc > tthresh)
                                         ? ((FT(1) - trans) / tau_loc - trans)
                                         : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
@@ -427,7 +432,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.ngas1 = (as.ngas + 1 > lk.n_gases) ? as.ngas + 1 : lk.n_gases;
     d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves;
     d.n_t_ref = lk.n_t_ref; d.n_p_ref = lk.n_pp - 1; d.n_t_plnk = lk.n_t_plnk; d.n_gases_ref = lk.n_gases;
-    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
+    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nslot0 = lk.m_nslot[0]; d.nslot1 = lk.m_nslot[1]; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 4 : 2; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");

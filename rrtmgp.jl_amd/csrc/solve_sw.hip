@@ -183,19 +183,24 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, inv_mu0, Rdir, Tdir, Rdif, Tdif);
                 const FT s_up = Rdir * t.dir_above, s_dn = Tdir * t.dir_above;
                 const FT den = m_rcp(FT(1) - t.beta * Rdif);
-                sw.at(k, voff) = Tdif * den;                       // U_{k+1} = A U_k + B
-                sw.at(k, voff + 1) = (Rdif * t.delta + s_up) * den;
-                sw.at(k, voff + 2) = t.beta;                       // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
+                sw.put(k, voff, Tdif * den);                       // U_{k+1} = A U_k + B
+                sw.put(k, voff + 1, (Rdif * t.delta + s_up) * den);
+                sw.put(k, voff + 2, t.beta);                       // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
                 const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
                 t.delta = s_dn + Tdif * den * (t.delta + t.beta * s_up);
                 t.beta = beta_n;
+#ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(t.delta * amask);
                 if (writer) { acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel; }
+#endif
                 t.dir_above = dir_k;
             };
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
+#ifdef RR_EXP_PREP_ONCE
+                if (c == nchunk - 1)
+#endif
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
@@ -239,8 +244,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
 #pragma unroll
                 for (int j = 0; j < DBT; j++) {
                     const int k = kl + j < nlay ? kl + j : nlay - 1;
-                    A[j] = sw.at(k, 0); B[j] = sw.at(k, 1); BE[j] = sw.at(k, 2);
-                    if (DIAG) { Ac[j] = sw.at(k, 3); Bc[j] = sw.at(k, 4); BEc[j] = sw.at(k, 5); }
+                    A[j] = sw.get(k, 0); B[j] = sw.get(k, 1); BE[j] = sw.get(k, 2);
+                    if (DIAG) { Ac[j] = sw.get(k, 3); Bc[j] = sw.get(k, 4); BEc[j] = sw.get(k, 5); }
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions
@@ -362,7 +367,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves;
     d.n_t_ref = lk.n_t_ref; d.n_p_ref = lk.n_pp - 1; d.n_t_plnk = lk.n_t_plnk; d.n_gases_ref = lk.n_gases;
-    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
+    d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nslot0 = lk.m_nslot[0]; d.nslot1 = lk.m_nslot[1]; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 6 : 3; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");

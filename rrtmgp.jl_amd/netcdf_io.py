@@ -7,10 +7,11 @@ Mirrors the constructors of the reference's `ext/lookup_constructors.jl`
 array of shape (d3, d2, d1); `Dataset.jl()` returns exactly that (the transposed view,
 Fortran-ordered), so every `permutedims` below carries the reference's axis numbers.
 
-Back ends, probed in this order: `netCDF4`, `h5netcdf`/`h5py` (NetCDF-4 files, which is
-what rrtmgp-data v1.9 ships) and `scipy.io.netcdf_file` (NetCDF-3 classic / 64-bit
-offset; convert with `nccopy -k classic in.nc out.nc`).  Only scipy is present in the
-build image, so the tests write classic files in the rrtmgp-data schema.
+Back ends: NetCDF-3 classic / 64-bit offset files go to `scipy.io.netcdf_file`; NetCDF-4 files
+(HDF5, what rrtmgp-data v1.9 ships) go to `netCDF4` or `h5py` when one is importable and otherwise
+to the built-in `hdf5_lite` reader (numpy + zlib only), so ingestion needs nothing beyond the data.
+The tests write classic files in the rrtmgp-data schema and NetCDF-4 files produced by the real HDF5
+library (tools/nc4_fixture_writer.py).
 """
 from __future__ import annotations
 
@@ -102,9 +103,10 @@ def _open(path):
             import h5py
             return "h5py", h5py.File(path, "r")
         except ImportError:
-            raise RuntimeError(
-                f"{path} is NetCDF-4/HDF5 and neither netCDF4 nor h5py is importable; convert it "
-                "with `nccopy -k classic` (scipy reads classic files) or install one of them")
+            pass
+        # dependency-free reader (numpy + zlib) for the HDF5 subset NetCDF-4 files use; same mini-interface as h5py
+        from . import hdf5_lite
+        return "h5py", hdf5_lite.File(path)
     raise RuntimeError(f"{path}: not a NetCDF file")
 
 

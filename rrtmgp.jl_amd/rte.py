@@ -19,23 +19,30 @@ from .states import (AtmosphericState, Flux, FluxBand, GrayAtmosphericState, LwB
                      julia_shape)
 
 
-class DeviceLookup:
-    """A lookup table uploaded to HBM (handle owned by this object)."""
+def _device_key(device):
+    """A device is an int (one GPU) or a sequence of ints (one shard per entry; ids may repeat)."""
+    return device if isinstance(device, int) else tuple(int(d) for d in device)
 
-    def __init__(self, host, device: int = 0):
+
+class DeviceLookup:
+    """A lookup table uploaded to HBM (handle owned by this object).  `device` may be a sequence of
+    device ids: one replica per distinct device behind one handle (`*_lookup_create_multi`)."""
+
+    def __init__(self, host, device=0):
         self.host = host
-        self.device = device
+        self.device = _device_key(device)
         self.handle = C.c_void_p()
         d = host.desc()
         L = _lib.lib()
-        if isinstance(host, GasLookup):
-            rc = L.rrtmgp_hip_gas_lookup_create(C.byref(d), device, C.byref(self.handle))
-        elif isinstance(host, LookUpCld):
-            rc = L.rrtmgp_hip_cloud_lookup_create(C.byref(d), device, C.byref(self.handle))
-        elif isinstance(host, LookUpAerosolMerra):
-            rc = L.rrtmgp_hip_aerosol_lookup_create(C.byref(d), device, C.byref(self.handle))
-        else:
+        kind = ("gas" if isinstance(host, GasLookup) else "cloud" if isinstance(host, LookUpCld)
+                else "aerosol" if isinstance(host, LookUpAerosolMerra) else None)
+        if kind is None:
             raise TypeError(type(host))
+        if isinstance(self.device, int):
+            rc = getattr(L, f"rrtmgp_hip_{kind}_lookup_create")(C.byref(d), self.device, C.byref(self.handle))
+        else:
+            ids = (C.c_int32 * len(self.device))(*self.device)
+            rc = getattr(L, f"rrtmgp_hip_{kind}_lookup_create_multi")(C.byref(d), ids, len(self.device), C.byref(self.handle))
         _lib.check(rc, "lookup upload")
 
     def __del__(self):
@@ -65,18 +72,29 @@ class Workspace:
     """Library-owned scratch for one (ncol, nlay, FT): what the reference keeps in
     `op`, `src`, `fluxb`, `state_cache` and the masks (src/rte/RTE.jl)."""
 
-    def __init__(self, ncol: int, nlay: int, dtype, device: int = 0):
-        self.ncol, self.nlay, self.dtype, self.device = ncol, nlay, np.dtype(dtype), device
+    def __init__(self, ncol: int, nlay: int, dtype, device=0):
+        """`device`: an int, or a sequence of device ids = one column shard per entry (ids may repeat), solved
+        concurrently inside the library (`rrtmgp_hip_workspace_create_multi`; host arrays, (nlev, ncol) fluxes)."""
+        self.ncol, self.nlay, self.dtype, self.device = ncol, nlay, np.dtype(dtype), _device_key(device)
         self.handle = C.c_void_p()
-        _lib.check(_lib.lib().rrtmgp_hip_workspace_create(device, ncol, nlay, _abi.ftype_of(dtype),
-                                                          C.byref(self.handle)), "workspace_create")
+        if isinstance(self.device, int):
+            _lib.check(_lib.lib().rrtmgp_hip_workspace_create(self.device, ncol, nlay, _abi.ftype_of(dtype),
+                                                              C.byref(self.handle)), "workspace_create")
+        else:
+            ids = (C.c_int32 * len(self.device))(*self.device)
+            _lib.check(_lib.lib().rrtmgp_hip_workspace_create_multi(ids, len(self.device), ncol, nlay, _abi.ftype_of(dtype),
+                                                                    C.byref(self.handle)), "workspace_create_multi")
+
+    @property
+    def n_shards(self) -> int:
+        return _lib.lib().rrtmgp_hip_workspace_shards(self.handle)
 
     def set_stream(self, stream_ptr: Optional[int]):
         _lib.check(_lib.lib().rrtmgp_hip_workspace_set_stream(self.handle, C.c_void_p(stream_ptr or 0)), "set_stream")
 
     def use_torch_stream(self):
         import torch
-        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)  # single-device workspaces only
 
     def synchronize(self):
         _lib.check(_lib.lib().rrtmgp_hip_workspace_synchronize(self.handle), "synchronize")
@@ -165,9 +183,9 @@ def _check_precision(slv: "_RTE", as_, *lookups):
         if host is not None and np.dtype(host.dtype) != want:
             raise TypeError(f"lookup tables are {np.dtype(host.dtype)}, the workspace was created for {want}")
     nlay, ncol = as_.dims
-    if nlay != slv.ws.nlay or ncol > slv.ws.ncol:
+    if nlay != slv.ws.nlay or ncol != slv.ws.ncol:  # the rule the library applies (check_common, api.hip)
         raise ValueError(f"state is (nlay={nlay}, ncol={ncol}); the workspace was created for "
-                         f"(nlay={slv.ws.nlay}, ncol<={slv.ws.ncol})")
+                         f"(nlay={slv.ws.nlay}, ncol={slv.ws.ncol})")
 
 
 def solve_lw(slv: _RTE, as_, lookup_lw=None, lookup_lw_cld=None, lookup_lw_aero=None, metric_scaling=None,
@@ -220,11 +238,25 @@ def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=
     return slv.flux
 
 
+def _check_extents(ws: Workspace, what: str, **arrays):
+    for name, (a, want) in arrays.items():
+        if a is None:
+            continue
+        got = tuple(julia_shape(a))
+        if got != tuple(want):
+            raise ValueError(f"{what}: {name} has shape {got}, the workspace was created for {tuple(want)}")
+        if np.dtype(array_dtype(a)) != ws.dtype:
+            raise TypeError(f"{what}: {name} is {np.dtype(array_dtype(a))}, the workspace was created for {ws.dtype}")
+
+
 def compute_col_gas(ws: Workspace, p_lev, params, vmr_h2o=None, lat=None, out=None):
     """compute_col_gas! (src/optics/column_amounts.jl:14-43) on the device."""
     nlev, ncol = julia_shape(p_lev)
     if out is None:
         out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
+    # the C entry point sizes every copy and launch from the workspace: the arrays must have exactly its extents
+    _check_extents(ws, "compute_col_gas", p_lev=(p_lev, (ws.nlay + 1, ws.ncol)), col_dry=(out, (ws.nlay, ws.ncol)),
+                   vmr_h2o=(vmr_h2o, (ws.nlay, ws.ncol)), lat=(lat, (ws.ncol,)))
     p, mem = array_ptr(p_lev)
     pd = params.desc()
     _lib.check(_lib.lib().rrtmgp_hip_compute_col_gas(ws.handle, mem, p, array_ptr(out)[0], C.byref(pd),
@@ -236,6 +268,9 @@ def compute_relative_humidity(ws: Workspace, p_lay, t_lay, params, vmr_h2o, out=
     """compute_relative_humidity! (src/optics/column_amounts.jl:52-76) on the device."""
     if out is None:
         out = np.empty(julia_shape(p_lay), dtype=array_dtype(p_lay), order="F")
+    full = (ws.nlay, ws.ncol)
+    _check_extents(ws, "compute_relative_humidity", rh=(out, full), p_lay=(p_lay, full), t_lay=(t_lay, full),
+                   vmr_h2o=(vmr_h2o, full))
     p, mem = array_ptr(p_lay)
     pd = params.desc()
     _lib.check(_lib.lib().rrtmgp_hip_compute_relative_humidity(ws.handle, mem, array_ptr(out)[0], p,

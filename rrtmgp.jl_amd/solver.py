@@ -113,7 +113,8 @@ class RRTMGPSolver:
         self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False) if diag else None
         self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True) if diag else None
         self.clear_net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F") if diag else None
-        self._seed = 0
+        self._seed = 0       # key of the counter-based McICA stream of the current update_fluxes call
+        self._rng_state = 0  # host generator the per-call keys are drawn from (the reference's global `Random` state)
 
     # ---- prepare_atmosphere!, update_fluxes.jl:252-281: one device launch -------------------------
     def prepare_atmosphere(self):
@@ -171,9 +172,17 @@ class RRTMGPSolver:
     # ---- update_fluxes!, update_fluxes.jl:223-233 ----------------------------------------------------
     def update_fluxes(self, seedval=None):
         m = self.radiation_method
-        # _maybe_reset_rng_seed!: here the seed keys the counter-based McICA stream
+        # _maybe_reset_rng_seed! (update_fluxes.jl:149-156): `Random.seed!(seedval)` only when the method asks for it
+        # AND a seed is given; otherwise the generator keeps advancing, so successive radiation steps draw
+        # independent McICA samples (frozen sampling would leave a persistent per-column bias).  Here one draw
+        # of a host splitmix64 generator keys the counter-based device stream of this call.
         if getattr(m, "reset_rng_seed", False) and seedval is not None:
-            self._seed = int(seedval)
+            self._rng_state = int(seedval) & 0xFFFFFFFFFFFFFFFF
+        self._rng_state = (self._rng_state + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self._rng_state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        self._seed = z ^ (z >> 31)
         self.prepare_atmosphere()
         self.update_lw_fluxes()
         self.update_sw_fluxes()

@@ -1,0 +1,87 @@
+"""Contracts of the C ABI beyond numerics:
+  * zero allocation per call once warm (update_fluxes.jl:215-218, test/standalone.jl:361-383): the library counts
+    every hipMalloc / hipFree / hipHostRegister it makes (`rrtmgp_hip_allocation_counts`); 100 warm solves must not
+    move the counters, for device-resident and for host-resident callers;
+  * different workspaces may be driven from different host threads at the same time (include/rrtmgp_hip.h,
+    SURVEY.md §8(b) "Threading") and give the single-thread bits."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from rrtmgp_jl_amd import _lib, rte, synthetic as S  # noqa: E402
+
+LWN = ("flux_up", "flux_dn", "flux_net")
+SWN = ("flux_up", "flux_dn", "flux_net", "flux_dn_dir")
+
+
+@pytest.mark.parametrize("where", ["host", "host-pipelined", "device", "shards"])
+def test_no_allocation_after_warm_up(tables32, where):
+    t = tables32
+    ncol = 16384 if where == "host-pipelined" else 96      # >= 16384 host columns take the chunked pipeline (api.hip)
+    nlay = 24
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=1, aerosols=True, night_fraction=0.1)
+    dev = [0, 0] if where == "shards" else 0
+    fdev = None
+    if where == "device":
+        import torch
+        d = torch.device("cuda", 0)
+        as_, lb, sb, fdev = as_.to_device(d), lb.to_device(d), sb.to_device(d), d
+    ws = rte.Workspace(ncol, nlay, np.float32, dev)
+    lw = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb, workspace=ws, flux_device=fdev)
+    sw = rte.TwoStreamSWRTE(ncol, nlay, np.float32, sb, workspace=ws, flux_device=fdev)
+    dl = {k: rte.DeviceLookup(t[k], dev) for k in ("lw", "sw", "cld_lw", "cld_sw", "aero_lw", "aero_sw")}
+
+    def step(seed):
+        rte.solve_lw(lw, as_, dl["lw"], dl["cld_lw"], dl["aero_lw"], seed=seed)
+        rte.solve_sw(sw, as_, dl["sw"], dl["cld_sw"], dl["aero_sw"], seed=seed)
+
+    for i in range(2):
+        step(i)
+    ws.synchronize()
+    before = _lib.allocation_counts()
+    for i in range(100 if ncol < 1000 else 6):
+        step(i)
+    ws.synchronize()
+    assert _lib.allocation_counts() == before, (before, _lib.allocation_counts())
+
+
+def test_two_workspaces_from_two_host_threads(tables64):
+    t = tables64
+    cases = []
+    for seed, ncol in ((1, 40), (2, 29)):
+        as_, lb, sb = S.make_columns(ncol, 30, np.float64, seed=seed, random_cld_frac=True, night_fraction=0.2)
+        cases.append((as_, lb, sb))
+    dl = {k: rte.DeviceLookup(t[k], 0) for k in ("lw", "sw", "cld_lw", "cld_sw")}
+
+    def run(case, reps, out):
+        as_, lb, sb = case
+        nlay, ncol = as_.dims
+        ws = rte.Workspace(ncol, nlay, np.float64, 0)
+        lw = rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb, workspace=ws)
+        sw = rte.TwoStreamSWRTE(ncol, nlay, np.float64, sb, workspace=ws)
+        try:
+            for _ in range(reps):
+                f_lw = rte.solve_lw(lw, as_, dl["lw"], dl["cld_lw"], seed=7)
+                f_sw = rte.solve_sw(sw, as_, dl["sw"], dl["cld_sw"], seed=7)
+            out.append(({n: f_lw.as_nlev_ncol(n).copy() for n in LWN}, {n: f_sw.as_nlev_ncol(n).copy() for n in SWN}))
+        except Exception as e:  # noqa: BLE001
+            out.append(e)
+
+    serial = []
+    for c in cases:
+        run(c, 1, serial)
+    results = [[], []]
+    threads = [threading.Thread(target=run, args=(cases[i], 25, results[i])) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(2):
+        assert len(results[i]) == 1 and not isinstance(results[i][0], Exception), results[i]
+        for n in LWN:
+            np.testing.assert_array_equal(results[i][0][0][n], serial[i][0][n])
+        for n in SWN:
+            np.testing.assert_array_equal(results[i][0][1][n], serial[i][1][n])

@@ -304,10 +304,11 @@ def test_rrtmgp_solver_update_fluxes_with_clear_sky_diagnostics(tables64):
     np.clip(ref_as.t_lev, lw.t_ref_min, lw.t_ref_max, out=ref_as.t_lev)
     ref_as.layerdata[0] = O.compute_col_gas(ref_as.p_lev, TEST_PARAMETERS, h2o, ref_as.lat)
     np.testing.assert_allclose(as_.layerdata[0], ref_as.layerdata[0], rtol=1e-13)
-    r_lw = O.solve_lw(ref_as, lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=42)
-    r_sw = O.solve_sw(ref_as, sb, t["sw"], t["cld_sw"], t["aero_sw"], seed=42)
-    c_lw = O.solve_lw(ref_as, lb, t["lw"], None, t["aero_lw"], seed=42)
-    c_sw = O.solve_sw(ref_as, sb, t["sw"], None, t["aero_sw"], seed=42)
+    key = s._seed   # the key this call drew from the host generator seeded with 42 (update_fluxes.jl:149-156)
+    r_lw = O.solve_lw(ref_as, lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=key)
+    r_sw = O.solve_sw(ref_as, sb, t["sw"], t["cld_sw"], t["aero_sw"], seed=key)
+    c_lw = O.solve_lw(ref_as, lb, t["lw"], None, t["aero_lw"], seed=key)
+    c_sw = O.solve_sw(ref_as, sb, t["sw"], None, t["aero_sw"], seed=key)
     tol = 1e-8
     assert np.abs(L2.lw_flux_up(s) - r_lw.flux_up).max() < tol and np.abs(L2.lw_flux_dn(s) - r_lw.flux_dn).max() < tol
     assert np.abs(L2.sw_flux_up(s) - r_sw.flux_up).max() < tol and np.abs(L2.sw_flux_dn(s) - r_sw.flux_dn).max() < tol
@@ -330,6 +331,11 @@ def test_rrtmgp_solver_update_fluxes_with_clear_sky_diagnostics(tables64):
     np.testing.assert_array_equal(L2.lw_flux_up(s), up1)
     L2.update_fluxes(s, 43)
     assert np.any(L2.lw_flux_up(s) != up1)
+    # without a seed the generator keeps advancing: successive steps draw independent McICA samples
+    L2.update_fluxes(s)
+    up2 = L2.lw_flux_up(s).copy()
+    L2.update_fluxes(s)
+    assert np.any(L2.lw_flux_up(s) != up2)
 
 
 def test_rrtmgp_solver_gray_and_constructor_errors():

@@ -51,3 +51,133 @@ def test_every_ccall_symbol_is_declared():
     assert len(syms) >= 14
     for s in syms:
         assert re.search(r"\b%s\s*\(" % s, header), s
+
+
+# ---- static checks of the method bodies and signatures (no Julia in the image) ----------------
+import json
+import sys
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import julia_lite as JLITE  # noqa: E402
+
+SIGS = json.load(open(os.path.join(ROOT, "tests", "golden", "julia_signatures.json")))
+
+
+def _module(src=JL):
+    return JLITE.parse_module(src)
+
+
+def _unresolved(src):
+    mod = _module(src)
+    names = mod.names()
+    bad = []
+    for m in mod.methods:
+        for nm, line in JLITE.unresolved_names(m, names):
+            bad.append((m.name, nm, line))
+    return bad
+
+
+def test_every_identifier_in_every_method_body_resolves():
+    """Each name used in a body is a parameter, a local, a module-level name (struct, const, import, method)
+    or a whitelisted Base name.  Round 1's glue used `band_flux` in three gray methods that do not take it."""
+    mod = _module()
+    assert len(mod.methods) >= 40 and len(mod.structs) >= 13, (len(mod.methods), len(mod.structs))
+    assert _unresolved(JL) == []
+
+
+def test_checker_catches_the_round1_defect():
+    """The checker must FAIL on a method that names something it does not have (the round-1 `band_flux` bug)."""
+    broken = JL.replace("flux_desc(flux_lw), opts()))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW",
+                        "flux_desc(flux_lw, band_flux), opts()))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW", 1)
+    assert broken != JL
+    bad = _unresolved(broken)
+    assert ("rte_lw_2stream_solve!", "band_flux") in {(m, n) for m, n, _ in bad}, bad
+
+
+def _device_methods(mod):
+    out = {}
+    for m in mod.methods:
+        if m.params and JLITE.norm_type(m.params[0].type) == "HIPDevice":
+            out.setdefault(m.name.split(".")[-1], []).append(m)
+    return out
+
+
+def test_device_methods_have_the_reference_signatures():
+    """For every device method of ext/cuda/*.jl (tests/golden/julia_signatures.json) the glue defines a method with
+    the same name, the same number of positional parameters and, parameter by parameter, the same type annotation
+    and default flag (the device type aside).  Catches arity drift and transposed arguments."""
+    mine = _device_methods(_module())
+    for ref in SIGS["methods"]:
+        cands = mine.get(ref["name"], [])
+        assert cands, f"no HIPDevice method {ref['name']} ({ref['file']}:{ref['line']})"
+        want = [(p["type"], p["default"], p["vararg"]) for p in ref["params"][1:]]
+        ok = False
+        for m in cands:
+            got = [(JLITE.norm_type(p.type), p.has_default, p.vararg) for p in m.params[1:]]
+            if got == want:
+                ok = True
+                # same parameter NAMES too where the glue spells them out (forwarders use args...)
+                names = [p.name for p in m.params[1:]]
+                if not any(p.vararg for p in m.params):
+                    assert names == [p["name"] for p in ref["params"][1:]], (ref["name"], names)
+        assert ok, (ref["name"], ref["file"], ref["line"], want,
+                    [[(JLITE.norm_type(p.type), p.has_default, p.vararg) for p in m.params[1:]] for m in cands])
+
+
+def test_flux_layout_rule_matches_the_reference_allocation():
+    """`_coalesced_2d` (src/optics/Fluxes.jl:45-49) dispatches on the ARRAY type: `Array` -> PermutedDimsArray over
+    a (nlev, ncol) parent, anything else -> plain (ncol, nlev).  The glue must pick RRTMGP_LAYOUT_NLEV_NCOL for the
+    first, RRTMGP_LAYOUT_NCOL_NLEV for the second, and hand over the PARENT's pointer of the wrapper."""
+    header = open(os.path.join(ROOT, "include", "rrtmgp_hip.h")).read()
+    c_layout = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (RRTMGP_LAYOUT_\w+)\s+(\d+)", header)}
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"const (LAYOUT_\w+) = Int32\((\d+)\)", JL)}
+    assert consts == {"LAYOUT_NCOL_NLEV": c_layout["RRTMGP_LAYOUT_NCOL_NLEV"],
+                      "LAYOUT_NLEV_NCOL": c_layout["RRTMGP_LAYOUT_NLEV_NCOL"]}
+    rule = {}
+    mod = _module()
+    for m in mod.methods:
+        if m.name == "flux_layout":
+            rule[JLITE.norm_type(m.params[0].type)] = "".join(t.text for t in m.body if t.kind != "nl")
+    perm = "PermutedDimsArray{T,2,(2,1),(2,1)}"
+    assert rule == {perm: "LAYOUT_NLEV_NCOL", "AbstractMatrix": "LAYOUT_NCOL_NLEV"}, rule
+    for entry in SIGS["coalesced_2d"]:
+        if entry["array_type"] == "Type{Array}":      # what array_type(::HIPDevice) returns
+            assert entry["wrapper"] == "PermutedDimsArray" and entry["parent_dims"] == ["d2", "d1"]   # (nlev, ncol) parent
+        else:
+            assert entry["wrapper"] == "none" and entry["parent_dims"] == ["d1", "d2"]                 # (ncol, nlev)
+    assert re.search(r"ClimaComms\.array_type\(::HIPDevice\) = Array", JL)
+    ptr_rule = {JLITE.norm_type(m.params[0].type): "".join(t.text for t in m.body if t.kind != "nl")
+                for m in mod.methods if m.name == "flux_ptr"}
+    assert ptr_rule == {perm: "ptr(parent(a))", "AbstractMatrix": "ptr(a)"}, ptr_rule
+    # and both flux descriptors use the rule for every flux array
+    for m in mod.methods:
+        if m.name == "flux_desc":
+            body = "".join(t.text for t in m.body if t.kind != "nl")
+            assert "flux_layout(f.flux_up)" in body and "ptr(f.flux_" not in body.replace("flux_ptr(f.flux_", "")
+
+
+def test_transposed_state_cache_is_switched_off_and_handles_are_released():
+    assert re.search(r"RRTMGP\.RTE\._default_state_cache\(::HIPDevice, gp::RRTMGP\.RRTMGPGridParams\) = nothing", JL)
+    assert "finalizer(release!, h)" in JL and "atexit(release_all!)" in JL
+    for sym in ("rrtmgp_hip_workspace_destroy", "rrtmgp_hip_lookup_destroy", "rrtmgp_hip_workspace_create_multi"):
+        assert f"(:{sym}, libhip[])" in JL, sym
+
+
+def test_ccall_argument_counts_match_the_header():
+    """Every ccall passes as many arguments as its type tuple declares, and as the C prototype takes."""
+    header = open(os.path.join(ROOT, "include", "rrtmgp_hip.h")).read()
+    toks = [t for t in JLITE.tokenize(JL) if t.kind != "nl"]
+    n_checked = 0
+    for i, t in enumerate(toks):
+        if t.kind == "id" and t.text == "ccall" and toks[i + 1].text == "(":
+            close = JLITE._matching(toks, i + 1)
+            args = JLITE._split_top(toks[i + 2:close], ",")
+            sym = args[0][1].text.lstrip(":")
+            types = JLITE._split_top(args[2][1:-1], ",")
+            assert len(args) - 3 == len(types), (sym, len(args) - 3, len(types))
+            proto = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % sym, header, flags=re.S)
+            assert proto, sym
+            c_args = [a for a in proto.group(1).split(",") if a.strip() and a.strip() != "void"]
+            assert len(c_args) == len(types), (sym, len(c_args), len(types))
+            n_checked += 1
+    assert n_checked >= 18, n_checked

@@ -1,0 +1,525 @@
+"""A small static reader for the subset of Julia used by ext/RRTMGPHIPExt.jl and by the
+reference's ext/cuda/*.jl method headers.  No Julia is available in the build image, so the
+glue is checked mechanically instead of being run (tests/test_julia_binding.py):
+
+  * `tokenize`          -- identifiers (Unicode), numbers, strings (with `$name` / `$(...)`
+                           interpolation kept as code), symbols, macros, operators, comments dropped;
+  * `top_level_items`   -- structs, consts, imports, `function ... end` and `name(args) = expr` methods;
+  * `Method`            -- name, positional parameters (name, type text, has default), keyword
+                           parameters, `where` variables, body tokens;
+  * `unresolved_names`  -- identifiers used in a method body that are neither parameters, locals,
+                           module-level names nor whitelisted Base names.
+
+It is deliberately conservative: anything it cannot classify is reported, so a clean run means
+every name in every body was accounted for.
+"""
+from __future__ import annotations
+
+import re
+import unicodedata
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+
+# ---------------------------------------------------------------------------- tokens
+@dataclass
+class Tok:
+    kind: str   # id, num, str, sym, macro, op, nl
+    text: str
+    line: int
+
+
+def _is_id_start(c: str) -> bool:
+    return c == "_" or c.isalpha() or (ord(c) > 127 and unicodedata.category(c)[0] in "LSN" and not c.isspace())
+
+
+def _is_id_char(c: str) -> bool:
+    return c in "_!" or c.isalnum() or (ord(c) > 127 and unicodedata.category(c)[0] in "LMNS")
+
+
+def tokenize(src: str) -> List[Tok]:
+    toks: List[Tok] = []
+    i, n, line = 0, len(src), 1
+    depth_stack: List[int] = []   # for `$(` interpolation: paren depth at which the string resumes
+
+    def push(kind, text):
+        toks.append(Tok(kind, text, line))
+
+    def read_string(j: int, triple: bool) -> int:
+        """src[j] is the first char after the opening quote(s); emits str / interpolated code tokens."""
+        nonlocal line
+        buf = []
+        while j < n:
+            if triple and src.startswith('"""', j):
+                push("str", "".join(buf)); return j + 3
+            if not triple and src[j] == '"':
+                push("str", "".join(buf)); return j + 1
+            c = src[j]
+            if c == "\\":
+                buf.append(src[j:j + 2]); j += 2; continue
+            if c == "$":
+                push("str", "".join(buf)); buf = []
+                if j + 1 < n and src[j + 1] == "(":
+                    # interpolated expression: tokenize up to the matching paren
+                    k, depth = j + 2, 1
+                    while k < n and depth:
+                        depth += src[k] == "("; depth -= src[k] == ")"; k += 1
+                    for t in tokenize(src[j + 2:k - 1]):
+                        toks.append(Tok(t.kind, t.text, line))
+                    j = k; continue
+                k = j + 1
+                while k < n and _is_id_char(src[k]) and src[k] != "!":
+                    k += 1
+                push("id", src[j + 1:k]); j = k; continue
+            if c == "\n":
+                line += 1
+            buf.append(c); j += 1
+        raise SyntaxError("unterminated string")
+
+    while i < n:
+        c = src[i]
+        if c == "\n":
+            push("nl", "\n"); line += 1; i += 1; continue
+        if c in " \t\r":
+            i += 1; continue
+        if c == "#":
+            if src.startswith("#=", i):
+                j = src.index("=#", i) + 2
+                line += src.count("\n", i, j); i = j; continue
+            while i < n and src[i] != "\n":
+                i += 1
+            continue
+        if src.startswith('"""', i):
+            i = read_string(i + 3, True); continue
+        if c == '"':
+            i = read_string(i + 1, False); continue
+        if c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            j = src.index("'", i + 1 + (src[i + 1] == "\\")) + 1
+            push("str", src[i:j]); i = j; continue
+        if c == "@":
+            j = i + 1
+            while j < n and (_is_id_char(src[j]) or src[j] == "."):
+                j += 1
+            push("macro", src[i:j]); i = j; continue
+        if c == ":" and i + 1 < n and _is_id_start(src[i + 1]) and (not toks or toks[-1].kind in ("op", "nl")
+                                                                    and toks[-1].text not in (")", "]", "}")):
+            # a quoted symbol (`:name`) rather than a range / ternary colon
+            if not (toks and toks[-1].text == ":"):
+                j = i + 1
+                while j < n and _is_id_char(src[j]):
+                    j += 1
+                push("sym", src[i:j]); i = j; continue
+        if _is_id_start(c):
+            j = i + 1
+            while j < n and _is_id_char(src[j]):
+                j += 1
+            # `x!=y` is not used in the glue; `name!` is an identifier character in Julia
+            push("id", src[i:j]); i = j; continue
+        if c.isdigit() or (c == "." and i + 1 < n and src[i + 1].isdigit()):
+            m = re.match(r"0x[0-9a-fA-F_]+|\d[\d_]*\.?\d*(?:[eEf][+-]?\d+)?", src[i:])
+            push("num", m.group(0)); i += len(m.group(0)); continue
+        for op in ("...", "===", "!==", "::", "->", "=>", "==", "!=", "<=", ">=", "&&", "||", "<:", ">:", ".=", ".*", ".+",
+                   ".-", "./", "+=", "-=", "*=", "/=", "|>", "≤", "≥"):
+            if src.startswith(op, i):
+                push("op", op); i += len(op); break
+        else:
+            push("op", c); i += 1
+    return toks
+
+
+# ---------------------------------------------------------------------------- structure
+OPEN, CLOSE = {"(": ")", "[": "]", "{": "}"}, {")", "]", "}"}
+BLOCK_OPENERS = {"function", "if", "for", "while", "let", "do", "begin", "try", "struct", "module", "quote", "macro"}
+
+
+@dataclass
+class Param:
+    name: Optional[str]
+    type: str          # text of the annotation, "" if none
+    has_default: bool
+    vararg: bool = False
+
+
+@dataclass
+class Method:
+    name: str
+    params: List[Param]
+    kwparams: List[Param]
+    where: List[str]
+    body: List[Tok]
+    line: int
+    short: bool
+
+
+@dataclass
+class Module:
+    methods: List[Method] = field(default_factory=list)
+    structs: dict = field(default_factory=dict)      # name -> [field names]
+    consts: List[str] = field(default_factory=list)
+    imports: List[str] = field(default_factory=list)
+    exports: List[str] = field(default_factory=list)
+
+    def names(self):
+        return set(self.consts) | set(self.imports) | set(self.structs) | {m.name.split(".")[-1] for m in self.methods}
+
+
+def _join(toks: List[Tok]) -> str:
+    out = []
+    for t in toks:
+        if t.kind == "nl":
+            continue
+        if out and t.text == "," :
+            out.append(", ")
+        else:
+            out.append(t.text)
+    return "".join(out).strip()
+
+
+def _split_top(toks: List[Tok], sep: str) -> List[List[Tok]]:
+    parts, cur, depth = [], [], 0
+    for t in toks:
+        if t.kind == "op" and t.text in OPEN:
+            depth += 1
+        elif t.kind == "op" and t.text in CLOSE:
+            depth -= 1
+        if depth == 0 and t.kind == "op" and t.text == sep:
+            parts.append(cur); cur = []
+        else:
+            cur.append(t)
+    if any(t.kind != "nl" for t in cur):
+        parts.append(cur)
+    return parts
+
+
+def _matching(toks: List[Tok], i: int) -> int:
+    """index of the bracket closing toks[i]"""
+    depth = 0
+    for j in range(i, len(toks)):
+        t = toks[j]
+        if t.kind == "op" and t.text in OPEN:
+            depth += 1
+        elif t.kind == "op" and t.text in CLOSE:
+            depth -= 1
+            if depth == 0:
+                return j
+    raise SyntaxError(f"unbalanced bracket at line {toks[i].line}")
+
+
+def _parse_param(toks: List[Tok]) -> Param:
+    toks = [t for t in toks if t.kind != "nl"]
+    has_default = False
+    depth = 0
+    for k, t in enumerate(toks):
+        if t.kind == "op" and t.text in OPEN:
+            depth += 1
+        elif t.kind == "op" and t.text in CLOSE:
+            depth -= 1
+        elif depth == 0 and t.kind == "op" and t.text == "=":
+            has_default = True
+            toks = toks[:k]
+            break
+    vararg = bool(toks) and toks[-1].text == "..."
+    if vararg:
+        toks = toks[:-1]
+    name, typ = None, ""
+    for k, t in enumerate(toks):
+        if t.kind == "op" and t.text == "::":
+            typ = _join(toks[k + 1:])
+            toks = toks[:k]
+            break
+    if toks:
+        if toks[0].text == "(":   # destructuring argument `(; a, b)::T`
+            name = _join(toks)
+        else:
+            name = toks[0].text
+    return Param(name, typ, has_default, vararg)
+
+
+def _parse_signature(toks: List[Tok], i: int) -> Tuple[str, List[Param], List[Param], List[str], int]:
+    """toks[i] starts the (possibly dotted) method name; returns (name, params, kwparams, where, index after)."""
+    j = i
+    name = ""
+    while toks[j].kind == "id" or (toks[j].kind == "op" and toks[j].text == "."):
+        name += toks[j].text; j += 1
+    assert toks[j].text == "(", (name, toks[j].text, toks[j].line)
+    close = _matching(toks, j)
+    inner = toks[j + 1:close]
+    halves = _split_top(inner, ";")
+    pos = [_parse_param(p) for p in _split_top(halves[0], ",")] if halves and halves[0] else []
+    # a leading `;` means keyword-only
+    if inner and inner[0].kind == "op" and inner[0].text == ";":
+        kw = pos; pos = []
+    else:
+        kw = [_parse_param(p) for p in _split_top(halves[1], ",")] if len(halves) > 1 else []
+    j = close + 1
+    where: List[str] = []
+    if j < len(toks) and toks[j].kind == "id" and toks[j].text == "where":
+        j += 1
+        if toks[j].text == "{":
+            e = _matching(toks, j)
+            where = [p[0].text for p in _split_top(toks[j + 1:e], ",") if p]
+            j = e + 1
+        else:
+            where = [toks[j].text]; j += 1
+    return name, pos, kw, where, j
+
+
+def _block_end(toks: List[Tok], i: int) -> int:
+    """toks[i] is a block opener keyword; returns the index of its matching `end`."""
+    depth = 0
+    j = i
+    while j < len(toks):
+        t = toks[j]
+        if t.kind == "op" and t.text in OPEN and t.text == "[":
+            j = _matching(toks, j) + 1   # `end` inside indexing is not a block end
+            continue
+        if t.kind == "id" and t.text in BLOCK_OPENERS:
+            # `if` / `for` inside a comprehension or generator are not block openers: they live inside brackets,
+            # which the bracket skip above handles for `[...]`; for `(x for x in y)` check the enclosing paren
+            depth += 1
+        elif t.kind == "id" and t.text == "end":
+            depth -= 1
+            if depth == 0:
+                return j
+        j += 1
+    raise SyntaxError(f"no matching end for block at line {toks[i].line}")
+
+
+def parse_module(src: str) -> Module:
+    toks = tokenize(src)
+    mod = Module()
+    i, n = 0, len(toks)
+    at_line_start = True
+    while i < n:
+        t = toks[i]
+        if t.kind == "nl":
+            at_line_start = True; i += 1; continue
+        if not at_line_start:
+            i += 1; continue
+        if t.kind == "id" and t.text in ("module", "baremodule"):
+            i += 2; continue                       # flat: the file is one module
+        if t.kind == "id" and t.text == "end":
+            i += 1; continue
+        if t.kind == "id" and t.text in ("import", "using"):
+            j = i + 1
+            stmt = []
+            while j < n and not (toks[j].kind == "nl" and (not stmt or stmt[-1].text not in (",", ":"))):
+                if toks[j].kind != "nl":
+                    stmt.append(toks[j])
+                j += 1
+            text = _join(stmt)
+            if ":" in [s.text for s in stmt]:
+                k = [s.text for s in stmt].index(":")
+                for part in _split_top(stmt[k + 1:], ","):
+                    mod.imports.append(part[-1].text)
+            elif " as " in " ".join(s.text for s in stmt):
+                mod.imports.append(stmt[-1].text)
+            else:
+                for part in _split_top(stmt, ","):
+                    mod.imports.append(part[0].text)        # `import A.B` binds A... and B
+                    mod.imports.append(part[-1].text)
+            i = j; continue
+        if t.kind == "id" and t.text == "export":
+            j = i + 1
+            while j < n and toks[j].kind != "nl":
+                if toks[j].kind == "id":
+                    mod.exports.append(toks[j].text)
+                j += 1
+            i = j; continue
+        if t.kind == "id" and t.text in ("struct", "mutable"):
+            k = i + (2 if t.text == "mutable" else 1)
+            name = toks[k].text
+            e = _block_end(toks, i + (1 if t.text == "mutable" else 0))
+            fields = []
+            body = toks[k + 1:e]
+            # skip `<: Super` on the header line
+            p = 0
+            while p < len(body) and body[p].kind != "nl":
+                p += 1
+            depth = 0
+            q = p
+            while q < len(body):
+                b = body[q]
+                if b.kind == "id" and b.text == "function":       # inner constructor
+                    q = _block_end(body, q) + 1; continue
+                if b.kind == "id" and q + 1 < len(body) and body[q + 1].text == "::" and depth == 0:
+                    fields.append(b.text)
+                q += 1
+            mod.structs[name] = fields
+            # inner constructors are methods too
+            q = p
+            while q < len(body):
+                if body[q].kind == "id" and body[q].text == "function":
+                    e2 = _block_end(body, q)
+                    nm, pos, kw, wh, after = _parse_signature(body, q + 1)
+                    mod.methods.append(Method(nm, pos, kw, wh, body[after:e2], body[q].line, False))
+                    q = e2 + 1
+                else:
+                    q += 1
+            i = e + 1; continue
+        if t.kind == "id" and t.text == "const":
+            mod.consts.append(toks[i + 1].text)
+            # skip to end of statement (balanced brackets)
+            j, depth = i, 0
+            while j < n:
+                if toks[j].kind == "op" and toks[j].text in OPEN:
+                    depth += 1
+                elif toks[j].kind == "op" and toks[j].text in CLOSE:
+                    depth -= 1
+                elif toks[j].kind == "nl" and depth == 0:
+                    break
+                j += 1
+            i = j; continue
+        if t.kind == "id" and t.text == "function":
+            e = _block_end(toks, i)
+            name, pos, kw, where, after = _parse_signature(toks, i + 1)
+            mod.methods.append(Method(name, pos, kw, where, toks[after:e], t.line, False))
+            i = e + 1; continue
+        if t.kind == "str":            # docstring
+            i += 1; continue
+        if t.kind == "id":
+            # short-form method `name(args) [where ...] = expr` (possibly continued over lines)
+            j = i
+            while toks[j].kind == "id" or (toks[j].kind == "op" and toks[j].text == "."):
+                j += 1
+            if toks[j].kind == "op" and toks[j].text == "(":
+                name, pos, kw, where, after = _parse_signature(toks, i)
+                if after < n and toks[after].kind == "op" and toks[after].text == "=":
+                    j, depth = after + 1, 0
+                    while j < n:
+                        tj = toks[j]
+                        if tj.kind == "op" and tj.text in OPEN:
+                            depth += 1
+                        elif tj.kind == "op" and tj.text in CLOSE:
+                            depth -= 1
+                        elif tj.kind == "nl" and depth == 0:
+                            prev = next((toks[k] for k in range(j - 1, after - 1, -1) if toks[k].kind != "nl"), None)
+                            if prev is None or not (prev.kind == "op" and prev.text in ("=", ",", "?", ":", "&&", "||", "+", "*")):
+                                break
+                        j += 1
+                    mod.methods.append(Method(name, pos, kw, where, toks[after + 1:j], t.line, True))
+                    i = j; continue
+        at_line_start = False
+        i += 1
+    return mod
+
+
+# ---------------------------------------------------------------------------- name resolution
+KEYWORDS = {"function", "end", "if", "else", "elseif", "for", "while", "return", "do", "in", "where", "let", "begin",
+            "try", "catch", "finally", "true", "false", "nothing", "new", "isa", "const", "local", "global", "break",
+            "continue", "struct", "mutable", "module", "import", "using", "export", "as", "∈"}
+# Base / Core names the glue is allowed to use
+BASE = {"ccall", "Ref", "Ptr", "Cvoid", "Cint", "Csize_t", "Int32", "Int64", "UInt64", "UInt8", "Float32", "Float64", "Int",
+        "Vector", "Array", "Matrix", "sizeof", "error", "unsafe_string", "pointer", "length", "size", "eltype", "isnothing",
+        "C_NULL", "get", "get!", "ENV", "rand", "enumerate", "Dict", "IdDict", "Tuple", "DataType", "NTuple", "Bool", "Any",
+        "AbstractArray", "AbstractMatrix", "Union", "Nothing", "Type", "copyto!", "nameof", "typeof", "finalizer", "parent",
+        "PermutedDimsArray", "GC", "undef", "String", "Integer", "atexit", "values", "foreach", "empty!", "Symbol", "zeros",
+        "min", "max", "first", "last", "vec", "Base", "Core", "convert", "ntuple", "all", "any", "isempty"}
+
+
+def _locals_of(m: Method) -> set:
+    """Names bound inside the body: assignment targets (incl. tuple destructuring), `for` variables,
+    `do` block arguments, closure arguments, `let` bindings, comprehension variables."""
+    b = [t for t in m.body]
+    loc = set()
+    n = len(b)
+    for i, t in enumerate(b):
+        if t.kind == "op" and t.text in ("=", "+=", "-=", "*=", "/=", ".=") and i > 0:
+            # walk left over an lvalue: `a`, `a, b`, `(a, b)`, `a::T`; stop at anything else
+            prev = b[i - 1]
+            # skip keyword arguments / named tuple fields: `f(x = 1)` -- inside parens of a call
+            j = i - 1
+            names = []
+            ok = True
+            while j >= 0:
+                tj = b[j]
+                if tj.kind == "id" and tj.text not in KEYWORDS:
+                    names.append((j, tj.text)); j -= 1
+                elif tj.kind == "op" and tj.text in (",", "(", ")"):
+                    j -= 1
+                else:
+                    break
+            # an lvalue must start its statement: the token before it is a newline, `;`, a block keyword or start
+            start = j
+            if start < 0 or b[start].kind == "nl" or (b[start].kind == "op" and b[start].text == ";") or \
+                    (b[start].kind == "id" and b[start].text in ("let", "begin", "local", "do", "else")):
+                # reject `f(a, b) = ...`-like call heads: a name directly followed by `(` is a call, not a target
+                for (k, nm) in names:
+                    if not (k + 1 < n and b[k + 1].kind == "op" and b[k + 1].text == "(" and k + 1 < i):
+                        loc.add(nm)
+        if t.kind == "id" and t.text == "for":
+            j = i + 1
+            while j < n and not (b[j].kind == "id" and b[j].text in ("in", "∈")) and not (b[j].kind == "op" and b[j].text == "="):
+                if b[j].kind == "id":
+                    loc.add(b[j].text)
+                j += 1
+        if t.kind == "id" and t.text == "do":
+            j = i + 1
+            while j < n and b[j].kind != "nl":
+                if b[j].kind == "id":
+                    loc.add(b[j].text)
+                j += 1
+        if t.kind == "op" and t.text == "->":
+            j = i - 1
+            if b[j].kind == "id":
+                loc.add(b[j].text)
+            elif b[j].text == ")":
+                depth = 0
+                while j >= 0:
+                    depth += b[j].text == ")"; depth -= b[j].text == "("
+                    if b[j].kind == "id":
+                        loc.add(b[j].text)
+                    if depth == 0:
+                        break
+                    j -= 1
+        if t.kind == "id" and t.text == "function" and i + 1 < n:   # nested function: its name and parameters
+            nm, pos, kw, wh, after = _parse_signature(b, i + 1)
+            loc.add(nm)
+            for p in pos + kw:
+                if p.name:
+                    loc.add(p.name)
+        # nested short-form closure `name(args) = expr` at statement start
+        if t.kind == "id" and i + 1 < n and b[i + 1].text == "(" and (i == 0 or b[i - 1].kind == "nl"):
+            try:
+                close = _matching(b, i + 1)
+            except SyntaxError:
+                continue
+            if close + 1 < n and b[close + 1].kind == "op" and b[close + 1].text == "=":
+                loc.add(t.text)
+                for part in _split_top(b[i + 2:close], ","):
+                    p = _parse_param(part)
+                    if p.name:
+                        loc.add(p.name)
+    return loc
+
+
+def unresolved_names(m: Method, module_names: set, extra: set = frozenset()) -> List[Tuple[str, int]]:
+    known = set(module_names) | BASE | KEYWORDS | set(extra) | set(m.where)
+    for p in m.params + m.kwparams:
+        if p.name:
+            for nm in re.findall(r"[^\W\d]\w*!?", p.name, flags=re.UNICODE):
+                known.add(nm)
+    known |= _locals_of(m)
+    out = []
+    b = m.body
+    for i, t in enumerate(b):
+        if t.kind != "id" or t.text in known:
+            continue
+        prev = b[i - 1] if i > 0 else None
+        nxt = b[i + 1] if i + 1 < len(b) else None
+        if prev is not None and prev.kind == "op" and prev.text == ".":
+            continue                                   # field / qualified access
+        if nxt is not None and nxt.kind == "op" and nxt.text == "=" and prev is not None and prev.kind == "op" \
+                and prev.text in ("(", ",", ";"):
+            continue                                   # keyword argument name in a call
+        out.append((t.text, t.line))
+    # names used in parameter TYPES and defaults must resolve too
+    for p in m.params + m.kwparams:
+        for mm in re.finditer(r"[^\W\d]\w*!?", p.type, flags=re.UNICODE):
+            if mm.group(0) not in known and not (mm.start() > 0 and p.type[mm.start() - 1] == "."):
+                out.append((mm.group(0), m.line))
+    return out
+
+
+def norm_type(t: str) -> str:
+    return re.sub(r"\s+", "", t)
