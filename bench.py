@@ -10,13 +10,25 @@ runs the same per-GPU workload (weak scaling); there is no collective on the dat
 A "step" is one `solve_lw` + `solve_sw` over the rank's batch with the state already
 resident in HBM (torch tensors handed to the C ABI as device pointers).
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` prices the dominant
-kernel's ALGORITHMIC HBM bytes against 8 TB/s as the task contract asks; the path is
-not HBM-bound, so the binding FP32-VALU figure is reported next to it.
+Prints ONE JSON line on rank 0.  Besides the contract's keys:
+  * `step_ms`: min / median / mean of the K timed steps (HIP events on the launch stream, read after the
+    timed region; the reference quotes BenchmarkTools' min for its ratchet and the median in its tables);
+  * `roofline`: the dominant kernel's ALGORITHMIC HBM bytes against 8 TB/s as the task contract asks; the path
+    is not HBM-bound (SURVEY.md F8), so the binding FP32-VALU figure is reported next to it as `valu`;
+    `traffic` comes from the committed rocprofv3 PMC summary and carries the git SHA it was taken at
+    (`traffic_source`; null when the summary is missing);
+  * `host_end_to_end`: the same workload handed over as HOST arrays (library stages H2D / D2H over PCIe
+    every step): never `value`;
+  * `precise_f32`: the IEEE-Float32 build of the library (-DRR_PRECISE_F32, correctly rounded div / sqrt);
+  * `variants`: Float64, MERRA aerosols, one-pass clear-sky diagnostic, 1 048 576 columns on one GPU;
+  * `cpu_baseline`: the plain-C oracle on a bounded sample of the same workload on this box's host cores.
+The extra legs run as short child processes after the timed region (rank 0, N = 1 only; `--no-legs` skips them).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -43,11 +55,11 @@ def algorithmic_bytes(nlay, nbnd_lw, nbnd_sw, ft_bytes):
     return lw * ft_bytes, sw * ft_bytes, step * ft_bytes
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ncol", type=int, default=NCOL_PER_GPU, help="columns per GPU")
     ap.add_argument("--nlay", type=int, default=NLAY)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -55,15 +67,40 @@ def main():
     ap.add_argument("--cld-frac", type=float, default=1.0, help="cloud fraction of cloudy layers (reference benchmark: 1)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="columns for the CPU baseline (0 disables)")
     ap.add_argument("--host", action="store_true",
-                    help="hand HOST arrays to the C ABI (library stages H2D/D2H every step): the PCIe-inclusive rate "
-                         "quoted in DESIGN.md, never the headline value")
+                    help="hand HOST arrays to the C ABI (library stages H2D/D2H every step): the PCIe-inclusive rate, "
+                         "never the headline value")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="with --host: ONE process drives this many column shards through a multi-device workspace "
+                         "(rrtmgp_hip_workspace_create_multi): device ids 0..n-1, wrapped onto the visible GPUs")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1: LW and SW kernels on torch's current stream; 2: each on its own stream (concurrent)")
     ap.add_argument("--clear-sky-diag", choices=["off", "one-pass", "two-solves"], default="off",
                     help="also produce clear-sky fluxes (AllSkyRadiationWithClearSkyDiagnostics): in the same launch, "
                          "or as the reference does with a second, cloudless solve.  Not the default workload.")
-    args = ap.parse_args()
+    ap.add_argument("--tile", type=int, default=1, help="repeat the generated columns this many times on the device "
+                                                        "(large single-GPU batches without the host-side generation cost)")
+    ap.add_argument("--no-legs", action="store_true", help="only the headline measurement (no variant / host / CPU legs)")
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)   # child-process mode: compact JSON, no legs
+    return ap.parse_args(argv)
 
+
+def run_leg(name, extra, env=None, timeout=600):
+    """One variant of the workload in a child process (its own library instance); returns its compact record."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--steps", "8", "--warmup", "2"] + extra
+    e = dict(os.environ)
+    e.update(env or {})
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
+        line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        return json.loads(line[-1])
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)[:300]}
+
+
+def main():
+    args = parse_args()
     import torch
     import rrtmgp_jl_amd  # noqa: F401
     from rrtmgp_jl_amd import _lib, rte, synthetic as S
@@ -91,25 +128,39 @@ def main():
             dist.init_process_group(backend)
 
     ft = np.float32 if args.dtype == "f32" else np.float64
-    ncol, nlay = args.ncol, args.nlay
+    ncol0, nlay = args.ncol, args.nlay
+    ncol = ncol0 * args.tile
     lw, sw = S.make_gas_lookup("lw", ft), S.make_gas_lookup("sw", ft)
     cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)
     al = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft) if args.aerosols else None
     asw = S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft) if args.aerosols else None
     col_offset = rank * ncol
-    as_h, lb_h, sb_h = S.make_columns(ncol, nlay, ft, seed=2026, col_offset=col_offset, clouds=True,
+    as_h, lb_h, sb_h = S.make_columns(ncol0, nlay, ft, seed=2026, col_offset=col_offset, clouds=True,
                                       cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
+    shards = None
     if args.host:
+        if args.tile != 1:
+            raise SystemExit("--tile is for device-resident runs")
         as_d, lb_d, sb_d = as_h, lb_h, sb_h
+        if args.shards > 0:
+            ndev = torch.cuda.device_count()
+            shards = [i % ndev for i in range(args.shards)]
     else:
         as_d, lb_d, sb_d = as_h.to_device(dev), lb_h.to_device(dev), sb_h.to_device(dev)
-    slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev)
-    slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=None if args.host else dev)
-    if args.streams == 1:
+        if args.tile > 1:   # ncol is the slowest (first torch) dimension of every per-column array
+            rep = lambda t: t if t is None or t.dim() == 0 or t.shape[0] != ncol0 else t.repeat(  # noqa: E731
+                (args.tile,) + (1,) * (t.dim() - 1)).contiguous()
+            as_d, lb_d, sb_d = as_d._map(rep), lb_d._map(rep), sb_d._map(rep)
+    wdev = shards if shards else local_rank
+    ws_lw = rte.Workspace(ncol, nlay, ft, wdev)
+    ws_sw = rte.Workspace(ncol, nlay, ft, wdev)
+    slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_lw)
+    slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_sw)
+    if args.streams == 1 and not shards:
         slv_lw.ws.use_torch_stream()
         slv_sw.ws.use_torch_stream()
-    d_lw, d_lw_cld, d_lw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (lw, cl, al))
-    d_sw, d_sw_cld, d_sw_aero = (rte.DeviceLookup(x, local_rank) if x is not None else None for x in (sw, cs, asw))
+    d_lw, d_lw_cld, d_lw_aero = (rte.DeviceLookup(x, wdev) if x is not None else None for x in (lw, cl, al))
+    d_sw, d_sw_cld, d_sw_aero = (rte.DeviceLookup(x, wdev) if x is not None else None for x in (sw, cs, asw))
 
     clr_lw = clr_sw = None
     if args.clear_sky_diag != "off":
@@ -140,19 +191,38 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    k_lw = k_sw = 0.0
+    # Per-step times: device-resident runs are stream-ordered, so events on the launch stream bracket each step and
+    # are read AFTER the timed region; host-array runs block inside the C ABI call, so the host clock is the step time.
+    on_torch_stream = args.streams == 1 and not args.host
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] \
+        if on_torch_stream else None
+    host_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events recorded by the library around each kernel on the launch stream
-        k_lw += slv_lw.ws.last_kernel_ms()
-        k_sw += slv_sw.ws.last_kernel_ms()
+    for i in range(args.steps):
+        if ev:
+            ev[i][0].record()
+            step()
+            ev[i][1].record()
+        else:
+            ts = time.perf_counter()
+            step()
+            if args.host:
+                host_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    per_step = [a.elapsed_time(b) for a, b in ev] if ev else host_ms
+
+    # kernel durations: HIP events recorded by the library around each launch on the launch stream, over three
+    # further steps OUTSIDE the timed region (reading them synchronises)
+    k_lw = k_sw = 0.0
+    for _ in range(3):
+        step()
+        k_lw += slv_lw.ws.last_kernel_ms() / 3
+        k_sw += slv_sw.ws.last_kernel_ms() / 3
 
     # sanity: results are finite and physical (never timed)
     up, sdn = torch.as_tensor(slv_lw.flux.flux_up), torch.as_tensor(slv_sw.flux.flux_dn)
@@ -162,7 +232,21 @@ def main():
     assert bool(torch.isfinite(sdn).all())
 
     if rank == 0:
-        ms_lw, ms_sw = k_lw / args.steps, k_sw / args.steps
+        value = world * ncol * args.steps / elapsed
+        step_ms = None
+        if per_step:
+            step_ms = {"min": min(per_step), "median": statistics.median(per_step), "mean": statistics.fmean(per_step),
+                       "n": len(per_step), "clock": "hip events on the launch stream" if ev else "host clock around the blocking call"}
+        if args.leg:   # child-process mode: a compact record for the parent's JSON line
+            rec = {"value": value, "unit": "columns/s", "ms_per_step": 1e3 * elapsed / args.steps,
+                   "lw_kernel_ms": k_lw, "sw_kernel_ms": k_sw, "ncol": ncol, "dtype": args.dtype,
+                   "library": os.path.basename(_lib.SO_PATH)}
+            if step_ms:
+                rec["min_ms"], rec["median_ms"] = step_ms["min"], step_ms["median"]
+                rec["value_at_min"] = ncol / (step_ms["min"] * 1e-3)
+            print(json.dumps(rec))
+            return
+        ms_lw, ms_sw = k_lw, k_sw
         ft_bytes = np.dtype(ft).itemsize
         b_lw, b_sw, b_step = algorithmic_bytes(nlay, lw.n_bnd, sw.n_bnd, ft_bytes)
         if args.aerosols:
@@ -174,20 +258,24 @@ def main():
         achieved = dom_bytes * ncol / (dom_ms * 1e-3) / 1e9
         flops = nlay * (lw.n_gpt * LW_FLOPS_PER_CELL + sw.n_gpt * SW_FLOPS_PER_CELL) * ncol
         valu_tflops = flops / ((ms_lw + ms_sw) * 1e-3) / 1e12
-        traffic = None
+        traffic = traffic_source = None
         prof = os.path.join(ROOT, "profiles", "latest.json")
-        if os.path.exists(prof) and not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32":
+        default_workload = (not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32"
+                            and not args.host and args.clear_sky_diag == "off")
+        if os.path.exists(prof) and default_workload:
             # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
-            # (tools/profile.sh -> tools/rocprof_summary.py): (2 * FETCH_SIZE + WRITE_SIZE) KB, the factor 2
+            # (tools/profile2.sh -> tools/rocprof_summary.py): (2 * FETCH_SIZE + WRITE_SIZE) KB, the factor 2
             # being the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md
             with open(prof) as fh:
                 pj = json.load(fh)
-            k = pj.get("kernels", {}).get("lw_solve_kernel" if ms_lw >= ms_sw else "sw_solve_kernel")
+            k = pj.get("kernels", {}).get(dom)
             if k and k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
                 traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+                traffic_source = {"profile": pj.get("source"), "git_sha": pj.get("git_sha"),
+                                  "profiled_kernel_ms": k.get("avg_us", 0.0) / 1e3}
         out = {
             "metric": "columns/sec, all-sky LW+SW 2-stream (nlay=64, 256+224 gpt)",
-            "value": world * ncol * args.steps / elapsed,
+            "value": value,
             "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -197,19 +285,39 @@ def main():
                                    f"{ncol} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
                                    f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, "
                                    f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}"
+                                   + (f", {len(shards)} shards in one process" if shards else "")
                                    + ("" if args.clear_sky_diag == "off" else f", + clear-sky diagnostic ({args.clear_sky_diag})"),
                        "ncol_per_gpu": ncol, "nlay": nlay, "ngpt_lw": lw.n_gpt, "ngpt_sw": sw.n_gpt,
                        "parallelism": f"columns sharded over {world} GPU(s), no collective"},
+            "step_ms": step_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_column": dom_bytes, "kernel_ms": dom_ms,
                          "note": "path is FP32-VALU/transcendental + table-gather bound, not HBM bound (SURVEY F8)"},
             "valu": {"achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": valu_tflops / VALU_PEAK_TFLOPS,
                      "algorithmic_flops_per_column": flops / ncol},
             "kernels": {"lw_solve_kernel_ms": ms_lw, "sw_solve_kernel_ms": ms_sw,
-                        "lw_bytes_per_column": b_lw, "sw_bytes_per_column": b_sw, "step_bytes_per_column": b_step},
+                        "lw_bytes_per_column": b_lw, "sw_bytes_per_column": b_sw, "step_bytes_per_column": b_step,
+                        "timing": "HIP events by the library around each launch, mean of 3 steps after the timed region"},
         }
+        legs = world == 1 and not args.no_legs and default_workload
+        if legs:
+            # free this process's device memory first: the children run on the same GPU
+            del as_d, lb_d, sb_d, slv_lw, slv_sw, ws_lw, ws_sw, d_lw, d_lw_cld, d_sw, d_sw_cld
+            torch.cuda.empty_cache()
+            out["host_end_to_end"] = run_leg("host", ["--host"])
+            out["host_end_to_end"]["note"] = ("same workload, HOST arrays staged H2D/D2H inside each solve (page-locked once, "
+                                              "chunked pipeline); never `value`")
+            precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
+            out["precise_f32"] = (run_leg("precise_f32", [], env={"RRTMGP_HIP_LIBRARY": precise}) if os.path.exists(precise)
+                                  else {"error": "libhip_rrtmgp_precise.so not built (make -C rrtmgp.jl_amd/csrc precise)"})
+            out["variants"] = {
+                "f64": run_leg("f64", ["--dtype", "f64"]),
+                "aerosols": run_leg("aerosols", ["--aerosols"]),
+                "clear_sky_diag": run_leg("clear_sky_diag", ["--clear-sky-diag", "one-pass"]),
+                "ncol_1048576": run_leg("ncol_1048576", ["--tile", "8", "--steps", "3", "--warmup", "1"]),
+            }
         # CPU baseline: the plain-C oracle (a port, not the Julia reference) on a bounded sample of
         # the same workload, on this box's host cores.  Rank 0, N = 1 only.
         sample = args.cpu_sample if args.cpu_sample is not None else (512 if world == 1 else 0)

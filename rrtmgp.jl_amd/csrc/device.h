@@ -264,14 +264,17 @@ constexpr int NBMAX = 16;  // bands per lookup the chunk records are laid out fo
 // base address, constant field offsets).
 template <typename FT>
 struct alignas(32) LayerRec {
-    FT fT, fP, col_dry, h2o;   // read together by the g-point lanes (one ds_read_b128 in Float32)
+    FT fP, ray_fac;            // read together with idx by the g-point lanes; ray_fac = (h2o + 1) col_dry (SW Rayleigh)
     int idx;                   // jT | jP << 8 | tropo << 16 (0-based lower T index, lower p plane, 0 = lower atm.)
+    FT fT;
+    FT col_dry, h2o;
     int aero_mask;
     int liq_loc, ice_loc;
     FT dens_fact, dry_fact, cld_frac, path_liq;
     FT path_ice, liq_fac, ice_fac, rh_f;
     int rh_loc, pl_lay_loc;
-    FT pl_lay_f, aod_t, aod_ts;  // aod_*: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
+    FT pl_lay_f, aod_t, aod_ts;
+    FT pad_;  // aod_*: per-layer (tau, tau*ssa) of the 550 nm band (SW with aerosols)
 };
 template <typename FT>
 struct LevelRec {
@@ -283,7 +286,8 @@ struct LevelRec {
 // array sits at a compile-time LDS offset.
 template <typename FT>
 struct alignas(32) ChunkFixed {
-    V4<FT> eta[CH * NBMAX];  // fe1, fe2, cm1, cm2
+    V4<FT> wgt[CH * NBMAX];  // (1-fe1)(1-fT), fe1 (1-fT), (1-fe2) fT, fe2 fT: the (eta, T) weights of interp2d / interp3d
+    V4<FT> amp[CH * NBMAX];  // col_dry * (cm1 (1-fP), cm1 fP, cm2 (1-fP), cm2 fP): column amounts x pressure weights
     V4<FT> cld[CH * NBMAX];  // cloud (tau, tau*ssa, tau*ssa*g, -) or (absorption tau, -, -, -)
     FT Blev[(CH + 1) * NBMAX];
     int je[CH * NBMAX];      // je1 | je2 << 8
@@ -455,6 +459,8 @@ __device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d,
         }
         rec.dens_fact = FT(0.01) * p / t;                // gas_optics.jl:368-370
         rec.dry_fact = FT(1) / (FT(1) + rec.h2o);        // gas_optics.jl:367
+        rec.ray_fac = (rec.h2o + FT(1)) * col_dry;       // compute_tau_rayleigh, gas_optics.jl:430-444
+        rec.pad_ = FT(0);
         rec.pl_lay_loc = 0; rec.pl_lay_f = FT(0);
         if (d.lw) planck_pos(t, lk.t_planck, lk.n_t_plnk, rec.pl_lay_loc, rec.pl_lay_f);
         rec.cld_frac = rec.path_liq = rec.path_ice = rec.liq_fac = rec.ice_fac = FT(0);
@@ -692,7 +698,12 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
             cm[it] = col_mix;
         }
         sh.ch->je[t] = je[0] | (je[1] << 8);
-        sh.ch->eta[t] = V4<FT>{fe[0], fe[1], cm[0], cm[1]};
+        {   // the weights every g-point of the band would form from (fT, fP, fe, col_mix): formed once here
+            const FT fT = sh.lay[k].fT, fP = sh.lay[k].fP, cd = sh.lay[k].col_dry;
+            const FT omfT = FT(1) - fT, omfP = FT(1) - fP;
+            sh.ch->wgt[t] = V4<FT>{(FT(1) - fe[0]) * omfT, fe[0] * omfT, (FT(1) - fe[1]) * fT, fe[1] * fT};
+            sh.ch->amp[t] = V4<FT>{(cm[0] * omfP) * cd, (cm[0] * fP) * cd, (cm[1] * omfP) * cd, (cm[1] * fP) * cd};
+        }
         if (d.lw) {
             sh.ch->Blev[t] = pl0 * (FT(1) - sh.lev[k].f) + pl1 * sh.lev[k].f;
             if (top_too) sh.ch->Blev[(kk + 1) * NBMAX + b] = pt0 * (FT(1) - sh.lev[k + 1].f) + pt1 * sh.lev[k + 1].f;
@@ -818,13 +829,13 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const LayerRec<FT> &L = sh.lay[k];
     const int li = L.idx;
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
-    const FT fT = L.fT, fP = L.fP, col_dry = L.col_dry;
+    const FT fP = L.fP, omfP = FT(1) - fP;
     const int r = kk * NBMAX + lb.ibnd;
     const unsigned jep = sh.ch->je[r];
     const unsigned je1 = jep & 0xff, je2 = jep >> 8;
-    const V4<FT> er = sh.ch->eta[r];
-    const FT fe1 = er.x, fe2 = er.y, cm1 = er.z, cm2 = er.w;
-    const FT omfT = FT(1) - fT, omfP = FT(1) - fP, omfe1 = FT(1) - fe1, omfe2 = FT(1) - fe2;
+    // band-level weights prepared once per (layer, band) by prepare_chunk
+    const V4<FT> wr = sh.ch->wgt[r], ar = sh.ch->amp[r];
+    const FT w11 = wr.x, w21 = wr.y, w12 = wr.z, w22 = wr.w;
     const unsigned NE = lk.n_eta, NG = lk.n_gpt;
     // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
     const unsigned sE = NG * EK, sP = NE * sE;
@@ -865,36 +876,56 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
     const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
     const unsigned gstep = lb.ngb * (MINOR_GROUP * E);  // byte distance between the groups of one g-point
     const FT *ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_GROUP;
-    const FT w11 = omfe1 * omfT, w21 = fe1 * omfT, w12 = omfe2 * fT, w22 = fe2 * fT;
-    auto minor_group = [&](unsigned x1, unsigned x2, const FT *sc4, bool wait) {
-        const V4<FT> c11 = ldg<V4<FT>>(kmn, x1), c21 = ldg<V4<FT>>(kmn + NCb, x1);
-        const V4<FT> c12 = ldg<V4<FT>>(kmn, x2), c22 = ldg<V4<FT>>(kmn + NCb, x2);
-        const V4<FT> sc = *reinterpret_cast<const V4<FT> *>(sc4);
-#ifndef RR_NO_GATHER_WAIT
-        // every gather of this layer has been issued: one wait instead of one per operand
-        if (wait) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
-#endif
-        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order
-        tau_minor += (w11 * c11.x + w21 * c21.x + w12 * c12.x + w22 * c22.x) * sc.x;
-        tau_minor += (w11 * c11.y + w21 * c21.y + w12 * c12.y + w22 * c22.y) * sc.y;
-        tau_minor += (w11 * c11.z + w21 * c21.z + w12 * c12.z + w22 * c22.z) * sc.z;
-        tau_minor += (w11 * c11.w + w21 * c21.w + w12 * c12.w + w22 * c22.w) * sc.w;
+    struct Corners { V4<FT> c11, c21, c12, c22; };
+    auto issue = [&](unsigned x1, unsigned x2) {
+        return Corners{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + NCb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + NCb, x2)};
     };
+    auto consume = [&](const Corners &c, const V4<FT> &sc) {
+        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order
+        tau_minor += (w11 * c.c11.x + w21 * c.c21.x + w12 * c.c12.x + w22 * c.c22.x) * sc.x;
+        tau_minor += (w11 * c.c11.y + w21 * c.c21.y + w12 * c.c12.y + w22 * c.c22.y) * sc.y;
+        tau_minor += (w11 * c.c11.z + w21 * c.c21.z + w12 * c.c12.z + w22 * c.c22.z) * sc.z;
+        tau_minor += (w11 * c.c11.w + w21 * c.c21.w + w12 * c.c12.w + w22 * c.c22.w) * sc.w;
+    };
+    auto scal = [&](int i0) { return *reinterpret_cast<const V4<FT> *>(ms + i0); };
 #ifndef RR_EXP_NO_MINOR
-    minor_group(a1, a2, ms, true);
+#ifndef RR_EXP_MINOR_ONE_GROUP
+    // Some band of this wavefront has a second group (5-8 contributors) in this region: its loads join the first
+    // group's ahead of the single wait; lanes of the other bands re-read their first group with zero scalings.
+    if (__any(n > MINOR_GROUP)) {
+        const bool mine = n > MINOR_GROUP;
+        const unsigned c = mine ? gstep : 0u;
+        const Corners g0 = issue(a1, a2), g1 = issue(a1 + c, a2 + c);
+        const V4<FT> s0 = scal(0);
+        V4<FT> s1 = scal(mine ? MINOR_GROUP : 0);
+        if (!mine) s1 = V4<FT>{FT(0), FT(0), FT(0), FT(0)};
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15): every gather of this layer has been issued
+        consume(g0, s0);
+        consume(g1, s1);
+        for (int i0 = 2 * MINOR_GROUP; i0 < n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases
+            const unsigned cc = __umul24((unsigned)(i0 / MINOR_GROUP), gstep);
+            consume(issue(a1 + cc, a2 + cc), scal(i0));
+        }
+    } else
+#endif
+    {
+        const Corners g0 = issue(a1, a2);
+        const V4<FT> s0 = scal(0);
+#ifndef RR_NO_GATHER_WAIT
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // one wait instead of one per operand
+#endif
+        consume(g0, s0);
+    }
 #else
     __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
-    for (int i0 = MINOR_GROUP; i0 < n; i0 += MINOR_GROUP) {  // further groups (bands with more than 4 minor gases)
-        const unsigned c = __umul24((unsigned)(i0 / MINOR_GROUP), gstep);
-        minor_group(a1 + c, a2 + c, ms + i0, false);
-    }
-    const FT tau_major = (cm1 * (omfP * (omfT * (omfe1 * k000 + fe1 * k100)) + fP * (omfT * (omfe1 * k010 + fe1 * k110))) +
-                          cm2 * (omfP * (fT * (omfe2 * q000 + fe2 * q100)) + fP * (fT * (omfe2 * q010 + fe2 * q110)))) *
-                         col_dry;
+    // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
+    // cm (1-fP) (1-fT) ((1-fe) k000 + fe k100) + ... regrouped as amp * (w11 k000 + w21 k100) + ...
+    const FT tau_major = ar.x * (w11 * k000 + w21 * k100) + ar.y * (w11 * k010 + w21 * k110) +
+                         ar.z * (w12 * q000 + w22 * q100) + ar.w * (w12 * q010 + w22 * q110);
     if (!SW) {
-        pfrac = (omfP * (omfT * (omfe1 * p000 + fe1 * p100)) + fP * (omfT * (omfe1 * p010 + fe1 * p110))) +
-                (omfP * (fT * (omfe2 * r000 + fe2 * r100)) + fP * (fT * (omfe2 * r010 + fe2 * r110)));
+        pfrac = omfP * ((w11 * p000 + w21 * p100) + (w12 * r000 + w22 * r100)) +
+                fP * ((w11 * p010 + w21 * p110) + (w12 * r010 + w22 * r110));
         tau = m_max(tau_major + tau_minor, FT(0));
         ssa = FT(0);
     } else {
@@ -902,9 +933,8 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
         const char *rc = lk.arena;
         const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
         const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
-        const FT kr = omfe1 * omfT * ldg<FT>(rc, r1) + fe1 * omfT * ldg<FT>(rc, r1 + sR) + omfe2 * fT * ldg<FT>(rc, r2) +
-                      fe2 * fT * ldg<FT>(rc, r2 + sR);
-        const FT tau_ray = kr * (L.h2o + FT(1)) * col_dry;
+        const FT kr = w11 * ldg<FT>(rc, r1) + w21 * ldg<FT>(rc, r1 + sR) + w12 * ldg<FT>(rc, r2) + w22 * ldg<FT>(rc, r2 + sR);
+        const FT tau_ray = kr * L.ray_fac;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
         ssa = tau_ray * m_rcp(tau);
         if (tau <= FT(0)) ssa = FT(0);
@@ -945,6 +975,36 @@ __device__ inline bool build_cloud_mask(const ColShared<FT> &sh, const ColDims &
 __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
     return k < 64 ? ((m0 >> k) & 1ULL) : ((m1 >> (k - 64)) & 1ULL);
 }
+// The layer loops visit the layers in order, so the mask is walked instead of indexed: one shift and one test per
+// layer (the 64-bit variable shift + select of mask_bit costs six VALU instructions).  UP: layers 0, 1, 2, ... (bit 0
+// is the current layer, shift right); otherwise nlay-1, nlay-2, ... (bit 63 is the current layer, shift left).
+template <bool UP>
+struct MaskWalk {
+    uint64_t cur, other;
+    int k;  // layer `cur` is positioned at (wave-uniform)
+    __device__ __forceinline__ MaskWalk(uint64_t m0, uint64_t m1, int nlay) {
+        if (UP) { cur = m0; other = m1; k = 0; }
+        else {
+            k = nlay - 1;
+            if (nlay > 64) { cur = m1 << (128 - nlay); other = m0; }
+            else { cur = m0 << (64 - nlay); other = 0; }
+        }
+    }
+    // the bit of layer `kq`, which must be the next one in walking order
+    __device__ __forceinline__ bool next(int kq) {
+        bool b;
+        if (UP) {
+            b = (unsigned)cur & 1u;
+            cur >>= 1;
+            if (kq == 63) cur = other;
+        } else {
+            b = (long long)cur < 0;
+            cur <<= 1;
+            if (kq == 64) cur = other;
+        }
+        return b;
+    }
+};
 
 // ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
 // recurrences are carried next to the all-sky ones) ----------------------------------------

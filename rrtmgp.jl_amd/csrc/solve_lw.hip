@@ -81,10 +81,10 @@ struct LwArgs {
 // cloud + aerosol increments of one layer for this lane (TwoStream), or their absorption only (OneScalar)
 template <typename FT, bool TWOSTREAM>
 __device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColShared<FT> &sh, const LaneBand &lb, int k,
-                                                    int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa, FT &g) {
+                                                    int kk, bool cloudy, FT &tau, FT &ssa, FT &g) {
     g = FT(0);
     const int r = kk * NBMAX + lb.ibnd;
-    if (d.has_cld && mask_bit(m0, m1, k)) {
+    if (d.has_cld && cloudy) {
         const V4<FT> c = sh.ch->cld[r];
         if (TWOSTREAM) increment_2stream(tau, ssa, g, c.x, c.y, c.z);
         else tau += c.x;
@@ -99,10 +99,10 @@ __device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColS
 // optics of one layer for this lane: gas, then the increments
 template <typename FT, bool TWOSTREAM>
 __device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColDims &d, const ColShared<FT> &sh,
-                                                const LaneBand &lb, int k, int kk, uint64_t m0, uint64_t m1, FT &tau, FT &ssa,
+                                                const LaneBand &lb, int k, int kk, bool cloudy, FT &tau, FT &ssa,
                                                 FT &g, FT &pfrac) {
     gas_optics<FT, false>(a.lk, sh, lb, k, kk, d.nbnd, tau, ssa, pfrac);
-    lw_layer_increments<FT, TWOSTREAM>(d, sh, lb, k, kk, m0, m1, tau, ssa, g);
+    lw_layer_increments<FT, TWOSTREAM>(d, sh, lb, k, kk, cloudy, tau, ssa, g);
 }
 
 constexpr int DB = 16;  // levels per batch of the top-down sweeps
@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
+        MaskWalk<true> mw(m0, m1, nlay);  // both LW solvers visit the layers bottom-up
 
         if (TWOSTREAM) {
             // ---- bottom-up: optics + sources, and one layer behind them coefficients + adding
@@ -203,12 +204,12 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     if (DIAG) {
                         gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
                         tau_c = tau; ssa_c = ssa;
-                        cld_k = d.has_cld && mask_bit(m0, m1, k);
-                        lw_layer_increments<FT, true>(d, sh, lb, k, kk, m0, m1, tau, ssa, gg);
-                        if (cld_k) lw_layer_increments<FT, true>(d, sh, lb, k, kk, 0, 0, tau_c, ssa_c, g_c);
+                        cld_k = d.has_cld && mw.next(k);
+                        lw_layer_increments<FT, true>(d, sh, lb, k, kk, cld_k, tau, ssa, gg);
+                        if (cld_k) lw_layer_increments<FT, true>(d, sh, lb, k, kk, false, tau_c, ssa_c, g_c);
                         else { tau_c = tau; ssa_c = ssa; g_c = gg; }
                     } else {
-                        lw_layer_optics<FT, true>(a, d, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                        lw_layer_optics<FT, true>(a, d, sh, lb, k, kk, d.has_cld && mw.next(k), tau, ssa, gg, pfrac);
                     }
                     const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, false>(a, d, sh, lb, k, kk, m0, m1, tau, ssa, gg, pfrac);
+                    lw_layer_optics<FT, false>(a, d, sh, lb, k, kk, d.has_cld && mw.next(k), tau, ssa, gg, pfrac);
                     const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
                     const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
                     const FT lay_src = sh.ch->Blay[kk * NBMAX + lb.ibnd] * pfrac;

@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             // one stream of the top-down adding: all-sky, and (DIAG) its clear-sky twin
             struct Stream { FT tau_cum, dir_above, beta, delta; };
             Stream S{FT(0), dir_top, FT(0), FT(0)}, C{FT(0), dir_top, FT(0), FT(0)};
+            MaskWalk<false> mw(m0, m1, nlay);  // top-down
             {
                 const FT s = seg_sum<BAND>(dir_top * amask);
                 if (writer) {
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                     FT tau, ssa, pf, gg = FT(0);
                     gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
                     FT tau_c = tau, ssa_c = ssa, g_c = FT(0);
-                    const bool cld_k = d.has_cld && mask_bit(m0, m1, k);
+                    const bool cld_k = d.has_cld && mw.next(k);
                     if (cld_k) { const V4<FT> cr = sh.ch->cld[r]; increment_2stream(tau, ssa, gg, cr.x, cr.y, cr.z); }
                     if (d.has_aero && sh.lay[k].aero_mask) {
                         const V4<FT> cr = sh.ch->aer[r];

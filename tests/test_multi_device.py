@@ -85,8 +85,9 @@ def test_noscat_gray_and_preparation_steps_on_shards(tables64):
     h2o = as_.vmr.vmr_h2o
     cd = rte.compute_col_gas(ws, as_.p_lev, params, h2o, as_.lat)
     np.testing.assert_allclose(cd, O.compute_col_gas(as_.p_lev, params, h2o, as_.lat), rtol=1e-13)
-    rh = rte.compute_relative_humidity(ws, as_.layerdata[1].copy(order="F"), as_.layerdata[2].copy(order="F"), params, h2o)
-    np.testing.assert_allclose(rh, O.compute_relative_humidity(as_.layerdata[1], as_.layerdata[2], params, h2o), rtol=1e-12)
+    p_lay, t_lay = np.asfortranarray(as_.layerdata[1]), np.asfortranarray(as_.layerdata[2])
+    rh = rte.compute_relative_humidity(ws, p_lay, t_lay, params, h2o)
+    np.testing.assert_allclose(rh, O.compute_relative_humidity(p_lay, t_lay, params, h2o), rtol=1e-12)
     # gray two-stream LW on shards == single
     gs = O.setup_gray_as_pr_grid(nlay, np.linspace(-60.0, 60.0, ncol), 100000.0, 9000.0, GrayOpticalThicknessSchneider2004(),
                                  params, np.float64)
