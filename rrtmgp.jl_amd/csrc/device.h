@@ -1006,6 +1006,19 @@ struct MaskWalk {
     }
 };
 
+// ---- column queue -------------------------------------------------------------------------------------
+// The persistent grid takes its first column statically (blockIdx.x) and every further one from a device-wide
+// counter: columns differ in cost (cloudy layers, minor-gas counts across the tropopause), and with a static
+// stride the launch ends when the unluckiest workgroup does.  Which workgroup solves a column does not enter the
+// result (per-workgroup scratch, McICA keyed by the global column).
+template <typename FT>
+__device__ __forceinline__ int next_column(const ColShared<FT> &sh, const ColDims &d, int *queue) {
+    __syncthreads();
+    if (threadIdx.x == 0) sh.misc[d.nwaves + 3] = (int)gridDim.x + atomicAdd(queue, 1);
+    __syncthreads();
+    return sh.misc[d.nwaves + 3];
+}
+
 // ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
 // recurrences are carried next to the all-sky ones) ----------------------------------------
 template <typename FT, int NV = 3>

@@ -71,6 +71,7 @@ struct LwArgs {
     const FT *sfc_emis;  // (nbnd, ncol)
     const FT *inc_flux;  // (ncol, ngpt) or nullptr
     FT *scratch;
+    int *queue;  // next column of the persistent grid (device counter, zeroed before the launch)
     ColDims dims;
     int n_angles;
     FT Ds[4], wts[4];
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     const int nchunk = (nlay + CH - 1) / CH;
     const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
 
-    for (int col = blockIdx.x; col < ncol; col += gridDim.x) {
+    for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
         prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
 
         uint64_t m0 = 0, m1 = 0;
@@ -391,7 +392,6 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
             a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
         }
-        __syncthreads();
     }
 }
 
@@ -456,9 +456,12 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    int rc = scratch_ensure(ws, (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT));
+    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT);
+    int rc = scratch_ensure(ws, sweep_bytes + 256);
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
+    a.queue = (int *)((char *)ws->scratch.ptr + sweep_bytes);
+    RR_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), ws->stream));
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
     RR_HIP(hipGetLastError());

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): latency / memory-pipe PMC passes of the default bench workload for one
-# library variant.  Usage: tools/profile2.sh <tag> [variant|base] [quick]   -> gpurun_out/prof_<tag>/summary.{txt,json}
+# library variant.  Run `git rev-parse HEAD > .git_sha` first (the GPU box has no .git).  Usage: tools/profile2.sh <tag> [variant|base]   -> gpurun_out/prof_<tag>/summary.{txt,json}
 # (the rocpd databases are deleted after they have been summarised: gpurun copies back at most 64 MiB)
 set -u
-TAG=${1:-x}; VAR=${2:-base}; QUICK=${3:-}
+TAG=${1:-x}; VAR=${2:-base}; 
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -17,15 +17,11 @@ PASSES=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
         "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC"
         "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
         "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT")
-if [ -z "$QUICK" ]; then
-  PASSES+=("TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
-           "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum")
-fi
 for pass in "${PASSES[@]}"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 200 rocprofv3 --pmc $pass --kernel-trace $SEL -d $OUT/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1 || echo "pass failed: $pass" >> $OUT/failed.txt
 done
-python $REPO/tools/rocprof_summary.py $OUT $OUT/summary.json > $OUT/summary.txt 2>&1
-( cd $REPO && git rev-parse HEAD 2>/dev/null || cat .git_sha 2>/dev/null ) > $OUT/sha.txt 2>/dev/null
+python $REPO/tools/rocprof_summary.py $OUT $OUT/summary.json "$(cat $REPO/.git_sha 2>/dev/null)" > $OUT/summary.txt 2>&1
+cp $REPO/.git_sha $OUT/sha.txt 2>/dev/null
 rm -rf $OUT/trace $OUT/pmc_*/ $OUT/*.log
 tail -3 $OUT/summary.txt

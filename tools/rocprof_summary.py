@@ -18,10 +18,10 @@ def q(dbp, sql):
         db.close()
 
 
-def to_json(root, path):
+def to_json(root, path, sha=None):
     """Per-kernel averages (duration in us, PMC counters per launch) as JSON for bench.py's `traffic`."""
     import json
-    out = {"source": root, "kernels": {}}
+    out = {"source": os.path.basename(root.rstrip("/")), "git_sha": sha or None, "kernels": {}}
     tr = os.path.join(root, "trace", "bench_results.db")
     if os.path.exists(tr):
         for name, calls, tot, avg, pct in q(tr, "select name, total_calls, total_duration, average, percentage from top_kernels"):
@@ -40,7 +40,7 @@ def to_json(root, path):
 
 
 def main(root):
-    print(f"# rocprofv3 summary of {root}")
+    print(f"# rocprofv3 summary of {os.path.basename(root.rstrip('/'))}" + (f" at git {sys.argv[3]}" if len(sys.argv) > 3 else ""))
     tr = os.path.join(root, "trace", "bench_results.db")
     if os.path.exists(tr):
         print("\n## kernel trace (--kernel-trace --stats): name, calls, total_us, avg_us, pct")
@@ -60,4 +60,4 @@ def main(root):
 if __name__ == "__main__":
     main(sys.argv[1])
     if len(sys.argv) > 2:
-        to_json(sys.argv[1], sys.argv[2])
+        to_json(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
