@@ -355,6 +355,10 @@ int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void
 #define RRTMGP_PREP_CLIP 4
 #define RRTMGP_PREP_COL_DRY 8
 #define RRTMGP_PREP_ALL 15
+/* optional, NOT part of prepare_atmosphere! (the reference's tests call compute_relative_humidity! themselves,
+ * test/read_clear_sky.jl:162-169): also refresh layerdata row 4 (rel_hum) from the clipped p_lay, t_lay, vmr_h2o in the
+ * same launch, compute_relative_humidity_kernel! src/optics/gas_optics.jl:58-80.  AtmosphericState only. */
+#define RRTMGP_PREP_REL_HUM 16
 
 #define RRTMGP_INTERP_NONE 0            /* NoInterpolation, interpolation.jl:47 */
 #define RRTMGP_INTERP_ARITHMETIC_MEAN 1 /* :55 */
@@ -385,6 +389,13 @@ int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state
  * (grid_adaptation.jl:147-156, 215-227); col_dry does not exist. */
 int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *as,
                                        const rrtmgp_params *params, const rrtmgp_prepare_opts *opts);
+
+/* compute_gray_heating_rate!(device::CUDADevice, hr_lay, p_lev, ncol, nlay, flux_net, cp_d_, grav_)
+ * ext/cuda/gray_atmosphere.jl:42-61 (body src/optics/GrayAtmosphere.jl:152-167; caller `heating_rate`,
+ * src/api/standalone.jl:106-122):  hr_lay(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d
+ * with flux_net, p_lev (nlev, ncol).  Dimensions are the workspace's. */
+int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev,
+                                         const void *flux_net, double cp_d, double grav);
 
 /* ---- several GPUs from ONE host process (SURVEY.md §8(b) "Threading", §8(e)) ---------------
  *

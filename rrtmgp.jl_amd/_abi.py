@@ -94,6 +94,7 @@ class PrepareOpts(C.Structure):
 
 
 PREP_INTERPOLATE, PREP_ISOTHERMAL, PREP_CLIP, PREP_COL_DRY, PREP_ALL = 1, 2, 4, 8, 15
+PREP_REL_HUM = 16   # optional extra step: relative humidity refreshed in the same launch
 INTERP = {"none": 0, "arithmetic_mean": 1, "geometric_mean": 2, "uniform_z": 3, "uniform_p": 4, "best_fit": 5}
 BOTTOM = {"same_as_interpolation": 0, "use_surface_temp_at_bottom": 1, "hydrostatic_bottom": 2}
 

@@ -46,6 +46,7 @@ EXPORTS = {
                                                       C.POINTER(_abi.SolveOpts)]),
     "rrtmgp_hip_compute_col_gas": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(_abi.Params), _P, _P]),
     "rrtmgp_hip_compute_relative_humidity": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(_abi.Params), _P]),
+    "rrtmgp_hip_compute_gray_heating_rate": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, C.c_double]),
     "rrtmgp_hip_prepare_atmosphere": (C.c_int, [_P, C.POINTER(_abi.AtmosState), C.POINTER(_abi.Params),
                                                 C.POINTER(_abi.PrepareOpts)]),
     "rrtmgp_hip_prepare_atmosphere_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), C.POINTER(_abi.Params),

@@ -894,6 +894,20 @@ static int rel_hum_t(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_
     return st.finish();
 }
 
+template <typename FT>
+static int heating_rate_t(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev, const void *flux_net, double cp_d,
+                          double grav) {
+    const size_t E = sizeof(FT), ncol = ws->ncol, nlay = ws->nlay;
+    Stager st{ws, {}};
+    const FT *pl, *fn;
+    FT *hr;
+    TRY(st.in(mem, S_PLEV, p_lev, (nlay + 1) * ncol * E, (const void **)&pl));
+    TRY(st.in(mem, S_FLUX_NET, flux_net, (nlay + 1) * ncol * E, (const void **)&fn));
+    TRY(st.out(mem, S_AUX0, hr_lay, nlay * ncol * E, (void **)&hr));
+    TRY(launch_heating_rate<FT>(ws, (int)ncol, (int)nlay, hr, fn, pl, grav, cp_d));
+    return st.finish();
+}
+
 }  // namespace rrtmgp
 
 using namespace rrtmgp;
@@ -1257,6 +1271,23 @@ int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? rel_hum_t<float>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o)
                                    : rel_hum_t<double>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o);
+}
+
+int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev,
+                                         const void *flux_net, double cp_d, double grav) {
+    RR_CHECK(ws && hr_lay && p_lev && flux_net, "null argument");
+    RR_CHECK(cp_d != 0.0, "cp_d must not be zero");
+    if (!ws->shards.empty()) {
+        const size_t nlay = (size_t)ws->nlay;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
+            const ColumnSlice sl{(size_t)ws->ftype, c0};
+            return rrtmgp_hip_compute_gray_heating_rate(sw, mem, sl.adv(hr_lay, nlay), sl.adv(p_lev, nlay + 1),
+                                                        sl.adv(flux_net, nlay + 1), cp_d, grav);
+        });
+    }
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? heating_rate_t<float>(ws, mem, hr_lay, p_lev, flux_net, cp_d, grav)
+                                   : heating_rate_t<double>(ws, mem, hr_lay, p_lev, flux_net, cp_d, grav);
 }
 
 int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_params *params,

@@ -212,6 +212,10 @@ template <typename FT>
 int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p_lay, const FT *t_lay,
                    const rrtmgp_params &ps, const FT *vmr_h2o);
 
+template <typename FT>
+int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, double grav,
+                        double cp_d);
+
 // prepare_atmosphere!: the state through layer / level accessors, so that AtmosphericState
 // (layerdata rows, element stride 4) and GrayAtmosphericState (separate arrays) share one kernel.
 template <typename FT>

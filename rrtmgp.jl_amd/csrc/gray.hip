@@ -274,6 +274,27 @@ __global__ void rel_hum_kernel(size_t n, FT *rh, const FT *p_lay, const FT *t_la
     rh[i] = m_max(FT(0.01) * (FT(0.263) * p_lay[i] * q_tmp) / es, FT(0));
 }
 
+// compute_gray_heating_rate_kernel!, src/optics/GrayAtmosphere.jl:152-167
+template <typename FT>
+__global__ void heating_rate_kernel(int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, FT grav, FT cp_d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ncol * nlay) return;
+    const size_t col = i / nlay, k = i - col * nlay, o = (size_t)(nlay + 1) * col + k;
+    hr_lay[i] = grav * (flux_net[o + 1] - flux_net[o]) / (p_lev[o + 1] - p_lev[o]) / cp_d;
+}
+template <typename FT>
+int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, double grav,
+                        double cp_d) {
+    const size_t n = (size_t)ncol * nlay;
+    const int tx = 256;
+    hipLaunchKernelGGL((heating_rate_kernel<FT>), dim3((unsigned)((n + tx - 1) / tx)), dim3(tx), 0, ws->stream, ncol, nlay, hr_lay,
+                       flux_net, p_lev, (FT)grav, (FT)cp_d);
+    RR_HIP(hipGetLastError());
+    return RRTMGP_OK;
+}
+template int launch_heating_rate<float>(rrtmgp_workspace *, int, int, float *, const float *, const float *, double, double);
+template int launch_heating_rate<double>(rrtmgp_workspace *, int, int, double *, const double *, const double *, double, double);
+
 template <typename FT>
 int launch_gray_lw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, const GrayArgs &ga, const FT *lat,
                    const FT *p_lay, const FT *p_lev, const FT *t_lay, const FT *t_lev, const FT *t_sfc,

@@ -135,6 +135,16 @@ __global__ void __launch_bounds__(64) prepare_kernel(const PrepView<FT> v, const
             v.col_dry[ls * (lay0 + k)] = (dp * a.avogadro / (FT(100 * 100) * m_air * g0));
         }
     }
+    if ((a.steps & RRTMGP_PREP_REL_HUM) && v.rel_hum && v.vmr_h2o) {  // compute_relative_humidity_kernel!, gas_optics.jl:58-80
+        const FT mwd = a.mol_m_h2o / a.mol_m_dry;
+        for (int k = lane; k < nlay_all; k += 64) {
+            const FT mmr = v.vmr_h2o[(size_t)v.hs * (lay0 + k)] * mwd;
+            const FT q_tmp = m_max(FT(1e-7), mmr / (FT(1) + mmr));
+            const FT t = t_lay[ls * k];
+            const FT es = m_exp((FT(17.67) * (t - FT(273.16))) / (t - FT(29.65)));
+            v.rel_hum[ls * (lay0 + k)] = m_max(FT(0.01) * (FT(0.263) * p_lay[ls * k] * q_tmp) / es, FT(0));
+        }
+    }
 }
 
 template <typename FT>

@@ -14,6 +14,12 @@
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
 #include "device.h"
 
+#ifdef RR_EXP_NO_CHUNK_BARRIER  // timing-only experiment: the chunk loop's barriers removed (races: results are wrong)
+#define RR_CHUNK_SYNC() ((void)0)
+#else
+#define RR_CHUNK_SYNC() __syncthreads()
+#endif
+
 namespace rrtmgp {
 
 // lw_2stream_coeffs, src/rte/longwave_2stream.jl:149-222
@@ -191,12 +197,12 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             };
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
-                __syncthreads();
+                RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE  // timing-only experiment: chunk records prepared for the first chunk only (barriers kept)
                 if (c == 0)
 #endif
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                __syncthreads();
+                RR_CHUNK_SYNC();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
@@ -323,7 +329,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                __syncthreads();
+                RR_CHUNK_SYNC();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;

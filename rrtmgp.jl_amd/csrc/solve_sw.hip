@@ -13,6 +13,12 @@
 // cloud-cover and 550 nm AOD diagnostics as the reference does.
 #include "device.h"
 
+#ifdef RR_EXP_NO_CHUNK_BARRIER  // timing-only experiment: the chunk loop's barriers removed (races: results are wrong)
+#define RR_CHUNK_SYNC() ((void)0)
+#else
+#define RR_CHUNK_SYNC() __syncthreads()
+#endif
+
 namespace rrtmgp {
 
 // sw_2stream_coeffs, src/rte/shortwave_2stream.jl:189-279
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
-                __syncthreads();
+                RR_CHUNK_SYNC();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk;
                     FT tau, ssa, pf;
@@ -199,12 +205,12 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             };
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CH, kn = min(CH, nlay - k0);
-                __syncthreads();
+                RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE
                 if (c == nchunk - 1)
 #endif
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
-                __syncthreads();
+                RR_CHUNK_SYNC();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
                     FT tau, ssa, pf, gg = FT(0);

@@ -97,10 +97,11 @@ def update_concentrations(ws, as_, params, idx_h2o=1):
 
 def prepare_atmosphere(ws, as_, params, lookup_lw=None, interpolation=NoInterpolation,
                        bottom_extrapolation=SameAsInterpolation, isothermal_boundary_layer=False, center_z=None,
-                       face_z=None):
+                       face_z=None, relative_humidity=False):
     """The whole cascade in one launch (update_fluxes.jl:252-281).  Bounds come from the longwave
     lookup (get_p_min / get_t_min / get_t_max, grid_adaptation.jl:22-53); gray states get p_min = 0
-    and no temperature clamp."""
+    and no temperature clamp.  `relative_humidity=True` also refreshes layerdata row 4 from the clipped state in
+    the same launch (compute_relative_humidity!, which the reference's drivers call separately)."""
     gray = isinstance(as_, GrayAtmosphericState)
     if not gray and lookup_lw is None:
         raise ValueError("a spectral state needs `lookup_lw` for its pressure / temperature bounds")
@@ -108,6 +109,8 @@ def prepare_atmosphere(ws, as_, params, lookup_lw=None, interpolation=NoInterpol
     t_min, t_max = (None, None) if gray else (lookup_lw.t_ref_min, lookup_lw.t_ref_max)
     idx_h2o = 1 if gray else lookup_lw.idx_h2o
     steps = _abi.PREP_ALL if interpolation != NoInterpolation else _abi.PREP_ALL & ~_abi.PREP_INTERPOLATE
+    if relative_humidity and not gray:
+        steps |= _abi.PREP_REL_HUM
     return _run(ws, as_, params, make_prepare_opts(steps, interpolation, bottom_extrapolation,
                                                    isothermal_boundary_layer, center_z, face_z, p_min, t_min, t_max,
                                                    idx_h2o))

@@ -277,3 +277,17 @@ def compute_relative_humidity(ws: Workspace, p_lay, t_lay, params, vmr_h2o, out=
                                                                array_ptr(t_lay)[0], C.byref(pd),
                                                                array_ptr(vmr_h2o)[0]), "compute_relative_humidity")
     return out
+
+
+def compute_gray_heating_rate(ws: Workspace, p_lev, flux_net, cp_d: float, grav: float, out=None):
+    """compute_gray_heating_rate! (src/optics/GrayAtmosphere.jl:133-167) on the device:
+    hr(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d."""
+    nlev, ncol = julia_shape(p_lev)
+    if out is None:
+        out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
+    lev = (ws.nlay + 1, ws.ncol)
+    _check_extents(ws, "compute_gray_heating_rate", p_lev=(p_lev, lev), flux_net=(flux_net, lev), hr_lay=(out, (ws.nlay, ws.ncol)))
+    p, mem = array_ptr(p_lev)
+    _lib.check(_lib.lib().rrtmgp_hip_compute_gray_heating_rate(ws.handle, mem, array_ptr(out)[0], p, array_ptr(flux_net)[0],
+                                                               float(cp_d), float(grav)), "compute_gray_heating_rate")
+    return out

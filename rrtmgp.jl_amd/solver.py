@@ -242,5 +242,5 @@ def surface_temperature(s): return s.as_.t_sfc
 
 def heating_rate(s: RRTMGPSolver):
     """heating_rate (src/api/standalone.jl:100-122): (g / cp) dF_net/dp per layer [K/s]; fresh array."""
-    nf, p = net_flux(s), to_host(level_pressure(s))
-    return np.asfortranarray(s.params.grav * (nf[1:] - nf[:-1]) / (p[1:] - p[:-1]) / s.params.cp_d).astype(s.dtype)
+    nf, p = np.asfortranarray(net_flux(s)), np.asfortranarray(to_host(level_pressure(s)))
+    return rte.compute_gray_heating_rate(s.lws.ws, p, nf, s.params.cp_d, s.params.grav)

@@ -243,6 +243,32 @@ def test_col_gas_and_relative_humidity():
                                    O.compute_relative_humidity(p_lay, t_lay, params, h2o), rtol=rtol)
 
 
+def test_gray_heating_rate_and_fused_relative_humidity(tables64):
+    """K12 compute_gray_heating_rate! (ext/cuda/gray_atmosphere.jl:42-61) on the device against the oracle, host and
+    device memory; and the optional RH step of the state-preparation launch against compute_relative_humidity!."""
+    import copy
+    from rrtmgp_jl_amd import grid_adaptation as GA
+    params = RRTMGPParameters()
+    for ft, rtol in [(np.float64, 1e-13), (np.float32, 2e-5)]:
+        as_, _, _ = S.make_columns(21, 30, ft, seed=4)
+        ws = rte.Workspace(21, 30, ft)
+        rng = np.random.default_rng(3)
+        fnet = np.asfortranarray(rng.normal(0.0, 50.0, (31, 21)).astype(ft))
+        ref = O.gray_heating_rate(fnet, as_.p_lev, params.grav, params.cp_d)
+        np.testing.assert_allclose(rte.compute_gray_heating_rate(ws, as_.p_lev, fnet, params.cp_d, params.grav), ref, rtol=rtol)
+    # fused RH: prepare_atmosphere(..., relative_humidity=True) == prepare_atmosphere + compute_relative_humidity
+    lw = tables64["lw"]
+    a, _, _ = S.make_columns(9, 24, np.float64, seed=6)
+    b = copy.deepcopy(a)
+    ws = rte.Workspace(9, 24, np.float64)
+    GA.prepare_atmosphere(ws, a, params, lw, relative_humidity=True)
+    GA.prepare_atmosphere(ws, b, params, lw)
+    rh = rte.compute_relative_humidity(ws, np.asfortranarray(b.layerdata[1]), np.asfortranarray(b.layerdata[2]), params,
+                                       b.vmr.vmr_h2o)
+    np.testing.assert_allclose(a.layerdata[3], rh, rtol=1e-13)
+    np.testing.assert_array_equal(a.layerdata[:3], b.layerdata[:3])
+
+
 # ---- full-size, size-independent properties (BASELINE config 4 shape) --------------------------
 def test_full_size_properties(tables32):
     t = tables32
