@@ -669,7 +669,10 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
                              const rrtmgp_solve_opts *opts, size_t E, F &&solve_chunk) {
     TRY(pipeline_resources(ws));
     const size_t ncol = as->ncol, nlev = as->nlay + 1;
-    const int nchunk = (int)std::min<size_t>(8, std::max<size_t>(2, ncol / 32768));
+    // chunk size: small enough that the first upload and the last download (the only copies nothing overlaps) are a
+    // small share, large enough that every chunk still fills the persistent grid several times over
+    static const size_t per_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 8192;
+    const int nchunk = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
     RR_HIP(hipStreamSynchronize(ws->stream));  // earlier work of the caller on this workspace
     Stager prev{ws, {}};
     prev.cs = ws->copy_stream;
