@@ -822,137 +822,169 @@ struct alignas(2 * sizeof(FT)) V2 {
     FT x, y;
 };
 
+// The gas optics of a layer come in two halves, so that a layer loop can put arithmetic that does not depend on
+// this layer's tables (the two-stream coefficients and the adding step of an EARLIER layer) between them:
+//   gas_issue  : LDS records -> gather addresses -> every gather of the layer in flight; nothing is consumed;
+//   gas_finish : ONE wait, then the interpolations.
+template <typename FT>
+struct Corners {
+    V4<FT> c11, c21, c12, c22;
+};
 template <typename FT, bool SW>
-__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
-                                           int nb, FT &tau, FT &ssa, FT &pfrac) {
+struct GasLoads {
+    FT k000, k100, k010, k110, q000, q100, q010, q110;   // kmajor corners (T plane 1: k, T plane 2: q)
+    FT p000, p100, p010, p110, r000, r100, r010, r110;   // planck_fraction corners (LW)
+    FT y11, y21, y12, y22;                               // Rayleigh corners (SW)
+    Corners<FT> g0, g1;                                  // minor-gas contributor groups
+    V4<FT> s0, s1, wr, ar;                               // their scalings; (eta, T) weights; amount x pressure weights
+    FT fP, ray_fac;
+    unsigned a1, a2, gstep, ncb;
+    const FT *ms;
+    int n;
+    bool two;
+};
+
+template <typename FT, bool SW>
+__device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb,
+                                                      int k, int kk) {
     constexpr unsigned E = sizeof(FT), EK = SW ? E : 2 * E;  // LW: (kmajor, planck_fraction) pairs
+    GasLoads<FT, SW> G;
     const LayerRec<FT> &L = sh.lay[k];
     const int li = L.idx;
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
-    const FT fP = L.fP, omfP = FT(1) - fP;
+    G.fP = L.fP;
+    G.ray_fac = SW ? L.ray_fac : FT(0);
     const int r = kk * NBMAX + lb.ibnd;
     const unsigned jep = sh.ch->je[r];
     const unsigned je1 = jep & 0xff, je2 = jep >> 8;
     // band-level weights prepared once per (layer, band) by prepare_chunk
-    const V4<FT> wr = sh.ch->wgt[r], ar = sh.ch->amp[r];
-    const FT w11 = wr.x, w21 = wr.y, w12 = wr.z, w22 = wr.w;
+    G.wr = sh.ch->wgt[r];
+    G.ar = sh.ch->amp[r];
     const unsigned NE = lk.n_eta, NG = lk.n_gpt;
     // interp3d, optics_utils.jl:136-181, on the [t][p][eta][gpt] layout
     const unsigned sE = NG * EK, sP = NE * sE;
     const unsigned row = (jT * lk.n_pp + jP) * NE;  // (t, p) row, in eta units
     const unsigned o1 = __umul24(row + je1, sE) + lb.gk;
     const unsigned o2 = __umul24(row + lk.n_pp * NE + je2, sE) + lb.gk;
-    FT k000, k100, k010, k110, q000, q100, q010, q110;
-    FT p000 = 0, p100 = 0, p010 = 0, p110 = 0, r000 = 0, r100 = 0, r010 = 0, r110 = 0;
     // the corner strides are wave-uniform: they go into the scalar base of the load, so that one VGPR
     // offset serves four loads
     const char *b0 = lk.arena, *b1 = lk.arena + sE, *b2 = lk.arena + sP, *b3 = lk.arena + sP + sE;
     if (SW) {
-        k000 = ldg<FT>(b0, o1); k100 = ldg<FT>(b1, o1); k010 = ldg<FT>(b2, o1); k110 = ldg<FT>(b3, o1);
-        q000 = ldg<FT>(b0, o2); q100 = ldg<FT>(b1, o2); q010 = ldg<FT>(b2, o2); q110 = ldg<FT>(b3, o2);
+        G.k000 = ldg<FT>(b0, o1); G.k100 = ldg<FT>(b1, o1); G.k010 = ldg<FT>(b2, o1); G.k110 = ldg<FT>(b3, o1);
+        G.q000 = ldg<FT>(b0, o2); G.q100 = ldg<FT>(b1, o2); G.q010 = ldg<FT>(b2, o2); G.q110 = ldg<FT>(b3, o2);
+        G.p000 = G.p100 = G.p010 = G.p110 = G.r000 = G.r100 = G.r010 = G.r110 = FT(0);
+        // compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners, issued with the others
+        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
+        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
+        G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
+        G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
     } else {
         const V2<FT> a = ldg<V2<FT>>(b0, o1), b = ldg<V2<FT>>(b1, o1);
         const V2<FT> c = ldg<V2<FT>>(b2, o1), d = ldg<V2<FT>>(b3, o1);
         const V2<FT> e = ldg<V2<FT>>(b0, o2), f = ldg<V2<FT>>(b1, o2);
         const V2<FT> g = ldg<V2<FT>>(b2, o2), h = ldg<V2<FT>>(b3, o2);
-        k000 = a.x; k100 = b.x; k010 = c.x; k110 = d.x; q000 = e.x; q100 = f.x; q010 = g.x; q110 = h.x;
-        p000 = a.y; p100 = b.y; p010 = c.y; p110 = d.y; r000 = e.y; r100 = f.y; r010 = g.y; r110 = h.y;
+        G.k000 = a.x; G.k100 = b.x; G.k010 = c.x; G.k110 = d.x; G.q000 = e.x; G.q100 = f.x; G.q010 = g.x; G.q110 = h.x;
+        G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
+        G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
     }
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
     // The contributors of a g-point sit in groups of MINOR_GROUP = 4 (build_gas): one 16-byte load per
     // interpolation corner and one 16-byte LDS read of the 4 scalings serve a whole group.  The first group is
-    // loaded UNCONDITIONALLY, right behind the kmajor corners and before anything is consumed: one exposed
-    // latency per layer, no exec masking.  Padding entries (a band without minor gases owns one all-padding group)
-    // are 0 in the table and carry a zero scaling, which leaves the in-order sum unchanged.
-    FT tau_minor = FT(0);
+    // loaded UNCONDITIONALLY, right behind the kmajor corners: no exec masking.  Padding entries (a band without minor
+    // gases owns one all-padding group) are 0 in the table and carry a zero scaling, which leaves the in-order sum
+    // unchanged.  When some band of this wavefront has a second group (5-8 contributors) in this region, its loads
+    // are issued too; lanes of the other bands re-read their first group with zero scalings.
 #ifdef RR_EXP_NO_MINOR  // timing-only experiment: no minor-gas gathers
-    const int n = 0;
+    G.n = 0;
 #else
-    const int n = lb.m_n(tropo);
+    G.n = lb.m_n(tropo);
 #endif
     const char *kmn = lk.arena;
     const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
-#ifndef RR_EXP_MINOR_ALIAS
-    const unsigned a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
-    const unsigned a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
-#endif
-#ifdef RR_EXP_MINOR_ALIAS  // timing-only experiment: the minor gathers read the kmajor rows (no cache lines of their own)
-    #define a1 (o1 & ~15u)
-    #define a2 (o2 & ~15u)
-#endif
-    const unsigned gstep = lb.ngb * (MINOR_GROUP * E);  // byte distance between the groups of one g-point
-    const FT *ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_GROUP;
-    struct Corners { V4<FT> c11, c21, c12, c22; };
-    auto issue = [&](unsigned x1, unsigned x2) {
-#ifdef RR_EXP_MINOR_HALF  // timing-only experiment: 8-byte instead of 16-byte gathers (same instruction count, half the bytes)
-        auto h = [&](const char *b, unsigned x) { const V2<FT> v = ldg<V2<FT>>(b, x); return V4<FT>{v.x, v.y, FT(0), FT(0)}; };
-        return Corners{h(kmn, x1), h(kmn + NCb, x1), h(kmn, x2), h(kmn + NCb, x2)};
-#elif defined(RR_EXP_MINOR_ALIAS)
-        return Corners{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + sE, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + sE, x2)};
-#else
-        return Corners{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + NCb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + NCb, x2)};
-#endif
+    G.a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
+    G.a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
+    G.gstep = lb.ngb * (MINOR_GROUP * E);  // byte distance between the groups of one g-point
+    G.ncb = NCb;
+    G.ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_GROUP;
+    auto corners = [&](unsigned x1, unsigned x2) {
+        return Corners<FT>{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + NCb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + NCb, x2)};
     };
-    auto consume = [&](const Corners &c, const V4<FT> &sc) {
+    const V4<FT> z4{FT(0), FT(0), FT(0), FT(0)};
+    G.g0 = G.g1 = Corners<FT>{z4, z4, z4, z4};
+    G.s0 = G.s1 = z4;
+    G.two = false;
+#ifndef RR_EXP_NO_MINOR
+    G.g0 = corners(G.a1, G.a2);
+    G.s0 = *reinterpret_cast<const V4<FT> *>(G.ms);
+#ifndef RR_EXP_MINOR_ONE_GROUP
+    G.two = __any(G.n > MINOR_GROUP);
+    if (G.two) {
+        const bool mine = G.n > MINOR_GROUP;
+        const unsigned c = mine ? G.gstep : 0u;
+        G.g1 = corners(G.a1 + c, G.a2 + c);
+        G.s1 = *reinterpret_cast<const V4<FT> *>(G.ms + (mine ? MINOR_GROUP : 0));
+        if (!mine) G.s1 = z4;
+    }
+#endif
+#endif
+    return G;
+}
+
+// `stores_after`: vector-memory stores issued BEHIND the gathers (the sweep records of an earlier layer).  vmcnt
+// retires in order, so waiting for "at most that many outstanding" covers every gather and leaves the stores in flight.
+template <typename FT, bool SW>
+__device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<FT, SW> &G, FT &tau, FT &ssa, FT &pfrac,
+                                           int stores_after = 0) {
+    constexpr unsigned E = sizeof(FT);
+    // every gather of this layer has been issued (some arithmetic ago): one wait instead of one per operand
+    if (stores_after == 3) __builtin_amdgcn_s_waitcnt(0x0F73);       // vmcnt(3) expcnt(7) lgkmcnt(15)
+    else if (stores_after == 6) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+    const FT w11 = G.wr.x, w21 = G.wr.y, w12 = G.wr.z, w22 = G.wr.w;
+    FT tau_minor = FT(0);
+    auto consume = [&](const Corners<FT> &c, const V4<FT> &sc) {
         // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order
         tau_minor += (w11 * c.c11.x + w21 * c.c21.x + w12 * c.c12.x + w22 * c.c22.x) * sc.x;
         tau_minor += (w11 * c.c11.y + w21 * c.c21.y + w12 * c.c12.y + w22 * c.c22.y) * sc.y;
         tau_minor += (w11 * c.c11.z + w21 * c.c21.z + w12 * c.c12.z + w22 * c.c22.z) * sc.z;
         tau_minor += (w11 * c.c11.w + w21 * c.c21.w + w12 * c.c12.w + w22 * c.c22.w) * sc.w;
     };
-    auto scal = [&](int i0) { return *reinterpret_cast<const V4<FT> *>(ms + i0); };
-#ifndef RR_EXP_NO_MINOR
-#ifndef RR_EXP_MINOR_ONE_GROUP
-    // Some band of this wavefront has a second group (5-8 contributors) in this region: its loads join the first
-    // group's ahead of the single wait; lanes of the other bands re-read their first group with zero scalings.
-    if (__any(n > MINOR_GROUP)) {
-        const bool mine = n > MINOR_GROUP;
-        const unsigned c = mine ? gstep : 0u;
-        const Corners g0 = issue(a1, a2), g1 = issue(a1 + c, a2 + c);
-        const V4<FT> s0 = scal(0);
-        V4<FT> s1 = scal(mine ? MINOR_GROUP : 0);
-        if (!mine) s1 = V4<FT>{FT(0), FT(0), FT(0), FT(0)};
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15): every gather of this layer has been issued
-        consume(g0, s0);
-        consume(g1, s1);
-        for (int i0 = 2 * MINOR_GROUP; i0 < n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases
-            const unsigned cc = __umul24((unsigned)(i0 / MINOR_GROUP), gstep);
-            consume(issue(a1 + cc, a2 + cc), scal(i0));
+    consume(G.g0, G.s0);
+    if (G.two) {
+        consume(G.g1, G.s1);
+        const char *kmn = lk.arena;
+        for (int i0 = 2 * MINOR_GROUP; i0 < G.n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases (rare; exposed)
+            const unsigned x1 = G.a1 + __umul24((unsigned)(i0 / MINOR_GROUP), G.gstep), x2 = x1 - G.a1 + G.a2;
+            const Corners<FT> c{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + G.ncb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + G.ncb, x2)};
+            consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0));
         }
-    } else
-#endif
-    {
-        const Corners g0 = issue(a1, a2);
-        const V4<FT> s0 = scal(0);
-#ifndef RR_NO_GATHER_WAIT
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // one wait instead of one per operand
-#endif
-        consume(g0, s0);
     }
-#else
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
     // cm (1-fP) (1-fT) ((1-fe) k000 + fe k100) + ... regrouped as amp * (w11 k000 + w21 k100) + ...
-    const FT tau_major = ar.x * (w11 * k000 + w21 * k100) + ar.y * (w11 * k010 + w21 * k110) +
-                         ar.z * (w12 * q000 + w22 * q100) + ar.w * (w12 * q010 + w22 * q110);
+    const FT tau_major = G.ar.x * (w11 * G.k000 + w21 * G.k100) + G.ar.y * (w11 * G.k010 + w21 * G.k110) +
+                         G.ar.z * (w12 * G.q000 + w22 * G.q100) + G.ar.w * (w12 * G.q010 + w22 * G.q110);
     if (!SW) {
-        pfrac = omfP * ((w11 * p000 + w21 * p100) + (w12 * r000 + w22 * r100)) +
-                fP * ((w11 * p010 + w21 * p110) + (w12 * r010 + w22 * r110));
+        const FT fP = G.fP, omfP = FT(1) - fP;
+        pfrac = omfP * ((w11 * G.p000 + w21 * G.p100) + (w12 * G.r000 + w22 * G.r100)) +
+                fP * ((w11 * G.p010 + w21 * G.p110) + (w12 * G.r010 + w22 * G.r110));
         tau = m_max(tau_major + tau_minor, FT(0));
         ssa = FT(0);
     } else {
-        // compute_tau_rayleigh, gas_optics.jl:430-444
-        const char *rc = lk.arena;
-        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
-        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
-        const FT kr = w11 * ldg<FT>(rc, r1) + w21 * ldg<FT>(rc, r1 + sR) + w12 * ldg<FT>(rc, r2) + w22 * ldg<FT>(rc, r2 + sR);
-        const FT tau_ray = kr * L.ray_fac;
+        const FT kr = w11 * G.y11 + w21 * G.y21 + w12 * G.y12 + w22 * G.y22;
+        const FT tau_ray = kr * G.ray_fac;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
         ssa = tau_ray * m_rcp(tau);
         if (tau <= FT(0)) ssa = FT(0);
         pfrac = FT(0);
     }
+    (void)E;
+}
+
+template <typename FT, bool SW>
+__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
+                                           int nb, FT &tau, FT &ssa, FT &pfrac) {
+    const GasLoads<FT, SW> G = gas_issue<FT, SW>(lk, sh, lb, k, kk);
+    gas_finish<FT, SW>(lk, G, tau, ssa, pfrac);
 }
 
 // ---- McICA mask for this lane's g-point: cloud_optics.jl:264-334 ----------------------------
