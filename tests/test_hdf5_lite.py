@@ -1,7 +1,8 @@
 """The dependency-free HDF5 / NetCDF-4 reader (rrtmgp_jl_amd/hdf5_lite.py) against files written by the REAL HDF5
 library with netCDF-C's creation properties (tools/nc4_fixture_writer.py):
 
-  * committed fixtures tests/golden/nc4_features_{v0,v2,v3}.nc — superblock 0 / 2 / 3, object headers v1 / v2, dense
+  * committed fixtures tests/golden/nc4_features_{v0,v2,v3,oldstyle}.nc — superblock 0 / 2 / 3, object headers v1 / v2,
+    old-style groups (symbol table + local heap: HDF5's defaults, e.g. h5py) and dense
     link storage (29 objects: fractal heap + v2 B-tree), dense attribute storage (12 attributes on one variable),
     chunked + shuffle + deflate (+ fletcher32) with ragged edge chunks, layout v3 (v1 B-tree index) and v4 (fixed
     array), contiguous, compact and scalar datasets, fixed-length strings, dimension scales with the reference-typed
@@ -29,7 +30,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 EXPECTED = np.load(os.path.join(GOLD, "nc4_features_expected.npz"))
 
 
-@pytest.mark.parametrize("tag,superblock", [("v0", 0), ("v2", 2), ("v3", 3)])
+@pytest.mark.parametrize("tag,superblock", [("v0", 0), ("v2", 2), ("v3", 3), ("oldstyle", 0)])
 def test_committed_fixtures_read_back_bit_for_bit(tag, superblock):
     f = hdf5_lite.File(os.path.join(GOLD, f"nc4_features_{tag}.nc"))
     assert f.buf[8] == superblock
@@ -40,6 +41,8 @@ def test_committed_fixtures_read_back_bit_for_bit(tag, superblock):
         assert a.shape == e.shape and a.dtype == e.dtype, name
         assert np.array_equal(a, e), name
         assert f[name].shape == e.shape
+    # netCDF-C tracks creation order -> new-style groups (link info 0x02); plain HDF5 defaults -> symbol table 0x11
+    assert (0x11 in [m for m, _ in f._root_msgs]) == (tag == "oldstyle")
     assert f["kmajor"]._layout[0] == (4 if tag == "v3" else 3) and f["kmajor"]._filters == [(2, (8,)), (1, (4,))]
     assert f["kminor_lower"]._filters[-1][0] == 3     # fletcher32
     # attributes: header-resident, dense (> 8 on one object), strings, numbers; reference-typed ones are skipped

@@ -98,15 +98,19 @@ NOT_A_VAR = b"This is a netCDF dimension but not a netCDF variable."
 class NC4Writer:
     """createDimension / createVariable in the style of netCDF-C's HDF5 layer."""
 
-    def __init__(self, path, libver=("earliest", "v18"), h5=None):
+    def __init__(self, path, libver=("earliest", "v18"), h5=None, track_order=True):
+        """`track_order=False` leaves HDF5's defaults (what h5py and plain HDF5 writers produce): old-style groups
+        (symbol table: v1 B-tree + local heap) and no creation-order indexes."""
         self.h5 = h5 or H5()
         L = self.h5.L
         bounds = {"earliest": 0, "v18": 1, "latest": 2 if not hasattr(L, "H5F_LIBVER_V110") else 2}
         fapl = L.H5Pcreate(self.h5.P_FILE_ACCESS)
         self.h5.ok(L.H5Pset_libver_bounds(fapl, bounds[libver[0]], bounds[libver[1]]), "libver bounds")
         fcpl = L.H5Pcreate(self.h5.P_FILE_CREATE)
-        self.h5.ok(L.H5Pset_link_creation_order(fcpl, CRT), "link creation order")
-        self.h5.ok(L.H5Pset_attr_creation_order(fcpl, CRT), "attr creation order")
+        self.track_order = track_order
+        if track_order:
+            self.h5.ok(L.H5Pset_link_creation_order(fcpl, CRT), "link creation order")
+            self.h5.ok(L.H5Pset_attr_creation_order(fcpl, CRT), "attr creation order")
         self.fid = self.h5.ok(L.H5Fcreate(path.encode(), 2, fcpl, fapl), "H5Fcreate")
         L.H5Pclose(fapl); L.H5Pclose(fcpl)
         self.dims = {}       # name -> (size, dataset id or None, dimid)
@@ -145,7 +149,8 @@ class NC4Writer:
     def _dcpl(self, shape, chunks, deflate, shuffle, fletcher):
         L = self.h5.L
         dcpl = L.H5Pcreate(self.h5.P_DATASET_CREATE)
-        L.H5Pset_attr_creation_order(dcpl, CRT)
+        if self.track_order:
+            L.H5Pset_attr_creation_order(dcpl, CRT)
         if chunks is not None and len(shape):
             c = (hsize_t * len(shape))(*chunks)
             self.h5.ok(L.H5Pset_chunk(dcpl, len(shape), c), "H5Pset_chunk")
@@ -247,11 +252,11 @@ def convert_classic(src, dst, libver=("earliest", "v18"), deflate=4, h5=None):
     w.close()
 
 
-def write_feature_fixture(path, libver, seed=0, h5=None):
+def write_feature_fixture(path, libver, seed=0, h5=None, track_order=True):
     """One small file carrying every on-disk feature the reader claims (see rrtmgp_jl_amd/hdf5_lite.py); returns the
     arrays written, by variable name."""
     rng = np.random.default_rng(seed)
-    w = NC4Writer(path, libver, h5)
+    w = NC4Writer(path, libver, h5, track_order)
     out = {}
 
     def put(name, arr, dims, **kw):
@@ -293,7 +298,11 @@ def main(outdir):
         p = os.path.join(outdir, f"nc4_features_{tag}.nc")
         arrs = write_feature_fixture(p, lv, seed=1, h5=h5)
         print(p, os.path.getsize(p), "bytes,", len(arrs), "variables")
-    np.savez_compressed(os.path.join(outdir, "nc4_features_expected.npz"), **arrs)   # the same arrays in all three
+    # HDF5 defaults instead of netCDF-C's creation-order tracking: old-style groups (symbol table + local heap)
+    p = os.path.join(outdir, "nc4_features_oldstyle.nc")
+    write_feature_fixture(p, ("earliest", "v18"), seed=1, h5=h5, track_order=False)
+    print(p, os.path.getsize(p), "bytes (old-style groups)")
+    np.savez_compressed(os.path.join(outdir, "nc4_features_expected.npz"), **arrs)   # the same arrays in all four
 
 
 if __name__ == "__main__":
