@@ -122,6 +122,8 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, c
         int n = 0;
         RR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds_bytes));
         it = ws->occupancy.emplace(key, std::max(n, 1)).first;
+        if (getenv("RRTMGP_HIP_TRACE_LAUNCH"))  // tuning aid: what decides the resident workgroups of this kernel variant
+            fprintf(stderr, "rrtmgp_hip: kernel %p: %d threads, %zu B LDS -> %d workgroups per CU\n", kernel, threads, lds_bytes, n);
     }
     const int per_cu = it->second;
     const int cap = ws->n_cu * per_cu;

@@ -24,6 +24,10 @@
 namespace rrtmgp {
 
 constexpr int CH = 16;  // layers per preparation chunk
+// ... of the kernel variant CA (clouds | aerosols << 1, -1 = run-time flags): the aerosol records would push the LDS
+// of a workgroup past a quarter of the CU's 160 KB (3 resident workgroups instead of 4), so those variants prepare
+// 8 layers at a time
+__host__ __device__ constexpr int chunk_layers(int ca) { return ca >= 2 ? CH / 2 : CH; }
 
 #ifndef RR_MIN_WAVES
 #define RR_MIN_WAVES 4  // waves per SIMD the column kernels are register-allocated for
@@ -284,22 +288,22 @@ struct LevelRec {
 
 // Band-level records of one chunk of CH layers, fixed strides (record r = kk * NBMAX + band), so every
 // array sits at a compile-time LDS offset.
-template <typename FT>
+template <typename FT, int CHK = CH>
 struct alignas(32) ChunkFixed {
-    V4<FT> wgt[CH * NBMAX];  // (1-fe1)(1-fT), fe1 (1-fT), (1-fe2) fT, fe2 fT: the (eta, T) weights of interp2d / interp3d
-    V4<FT> amp[CH * NBMAX];  // col_dry * (cm1 (1-fP), cm1 fP, cm2 (1-fP), cm2 fP): column amounts x pressure weights
-    V4<FT> cld[CH * NBMAX];  // cloud (tau, tau*ssa, tau*ssa*g, -) or (absorption tau, -, -, -)
-    FT Blev[(CH + 1) * NBMAX];
-    int je[CH * NBMAX];      // je1 | je2 << 8
+    V4<FT> wgt[CHK * NBMAX];  // (1-fe1)(1-fT), fe1 (1-fT), (1-fe2) fT, fe2 fT: the (eta, T) weights of interp2d / interp3d
+    V4<FT> amp[CHK * NBMAX];  // col_dry * (cm1 (1-fP), cm1 fP, cm2 (1-fP), cm2 fP): column amounts x pressure weights
+    V4<FT> cld[CHK * NBMAX];  // cloud (tau, tau*ssa, tau*ssa*g, -) or (absorption tau, -, -, -)
+    FT Blev[(CHK + 1) * NBMAX];
+    int je[CHK * NBMAX];      // je1 | je2 << 8
     FT pad[NBMAX];           // keeps the tail 32-byte aligned
     // the tail is only allocated as far as it is used (carve_shared):
-    FT Blay[CH * NBMAX];     // layer Planck sources: no-scattering LW only
-    V4<FT> aer[CH * NBMAX];  // aerosol (tau, tau*ssa, tau*ssa*g, -): only with an aerosol lookup
+    FT Blay[CHK * NBMAX];     // layer Planck sources: no-scattering LW only
+    V4<FT> aer[CHK * NBMAX];  // aerosol (tau, tau*ssa, tau*ssa*g, -): only with an aerosol lookup
 };
 
-template <typename FT>
+template <typename FT, int CHK = CH>
 struct ColShared {
-    ChunkFixed<FT> *ch;  // LDS offset 0
+    ChunkFixed<FT, CHK> *ch;  // LDS offset 0
     LayerRec<FT> *lay;   // constant offset
     LevelRec<FT> *lev;   // [nlev]
     FT *vmr;             // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
@@ -322,20 +326,20 @@ __host__ __device__ inline T *carve(char *&p, size_t n) {
     return r;
 }
 
-template <typename FT>
-__host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, const ColDims &d) {
+template <typename FT, int CHK>
+__host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base, const ColDims &d) {
     char *p = base;
-    s.ch = carve<ChunkFixed<FT>>(p, 1);
+    s.ch = carve<ChunkFixed<FT, CHK>>(p, 1);
     // drop the unused tail of the chunk record: aer, and Blay when neither is needed (both multiples of 32 bytes)
     if (!d.has_aero) {
-        p -= sizeof(V4<FT>) * CH * NBMAX;
-        if (!(d.lw && !d.twostream)) p -= sizeof(FT) * CH * NBMAX;
+        p -= sizeof(V4<FT>) * CHK * NBMAX;
+        if (!(d.lw && !d.twostream)) p -= sizeof(FT) * CHK * NBMAX;
     }
     s.lay = carve<LayerRec<FT>>(p, d.nlay);
     s.lev = carve<LevelRec<FT>>(p, d.nlev);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
     s.mscale_row = d.max_int;
-    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_GROUP) * CH);
+    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_GROUP) * CHK);
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
@@ -353,8 +357,8 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT> &s, char *base, con
 }
 
 // Fill the TabCache (once per workgroup) and return a lookup view whose small-table pointers are the LDS copies.
-template <typename FT>
-__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk,
+template <typename FT, int CHK>
+__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT, CHK> &sh, const ColDims &d, const DevGas<FT> &lk,
                                                 const DevState<FT> &as) {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (as.vmr_kind == RRTMGP_VMR_GM)
@@ -425,8 +429,8 @@ __device__ __forceinline__ void cld_pos(FT re, FT r_lwr, FT r_upr, int nsize, in
     loc = l - 1;
 }
 
-template <typename FT>
-__device__ inline void prepare_column(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk,
+template <typename FT, int CHK>
+__device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDims &d, const DevGas<FT> &lk,
                                       const DevCld<FT> *cld, const DevAero<FT> *aero, const DevState<FT> &as, int col) {
     const int nlay = d.nlay, nlev = d.nlev, tid = threadIdx.x, nt = blockDim.x;
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
@@ -560,8 +564,8 @@ __device__ __forceinline__ void delta_scale(FT &tau, FT &ssa, FT &g) {
 }
 
 // ---- cloud optics of one (layer, band): cloud_optics.jl:154-244 -----------------------------
-template <typename FT>
-__device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShared<FT> &sh, int ibnd, int ice_rgh, int k,
+template <typename FT, int CHK>
+__device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShared<FT, CHK> &sh, int ibnd, int ice_rgh, int k,
                                             FT &tl, FT &tls, FT &tlsg, FT &ti, FT &tis, FT &tisg) {
     tl = tls = tlsg = ti = tis = tisg = FT(0);
     const LayerRec<FT> &L = sh.lay[k];
@@ -587,8 +591,8 @@ __device__ __forceinline__ void cloud_props(const DevCld<FT> &lc, const ColShare
 }
 
 // ---- aerosol optics of one (layer, band): aerosol_optics.jl:141-431 --------------------------
-template <typename FT>
-__device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT> &sh, const FT *mass, const FT *size,
+template <typename FT, int CHK>
+__device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT, CHK> &sh, const FT *mass, const FT *size,
                                       int ibnd, int k, FT &tc, FT &tsc, FT &tsgc) {
     const int nrh = la.nrh, nbin = la.nbin;
     const int loc = sh.lay[k].rh_loc;
@@ -647,15 +651,15 @@ __device__ inline void lookup_aerosol(const DevAero<FT> &la, const ColShared<FT>
 
 // ---- (layer, band) records for layers [k0, k0 + kn) -------------------------------------------
 // Callers synchronise the workgroup before (previous chunk fully consumed) and after.
-template <typename FT>
-__device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, const DevGas<FT> &lk,
+template <typename FT, int CHK>
+__device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims &d, const DevGas<FT> &lk,
                                      const DevCld<FT> *cld, const DevAero<FT> *aero, const DevState<FT> &as, int col,
                                      int k0, int kn, bool delta) {
     const int nlay = d.nlay, nb = d.nbnd, tid = threadIdx.x, nt = blockDim.x;
     const int NE = lk.n_eta;
-    for (int u = tid; u < CH * nb; u += nt) {
+    for (int u = tid; u < CHK * nb; u += nt) {
 #ifdef RR_PREP_KK_MINOR
-        const int b = u / CH, kk = u % CH, k = k0 + kk;  // CH is a power of two
+        const int b = u / CHK, kk = u % CHK, k = k0 + kk;  // CHK is a power of two
 #else
         // consecutive lanes take consecutive bands of one layer: the record stores below are contiguous in LDS
         // (16-byte stride between lanes instead of 256) and the sh.lay[k] / sh.lev[k] reads are broadcasts
@@ -754,7 +758,7 @@ __device__ inline void prepare_chunk(const ColShared<FT> &sh, const ColDims &d, 
     // minor-gas scalings, compute_tau_minor gas_optics.jl:364-396; 0 where the gas is absent (vmr <= 0) and in the
     // padding slots.  Row kk holds the slots of layer k0 + kk: consecutive lanes write consecutive words.
     const int S = d.max_int;
-    for (int t = tid; t < S * CH; t += nt) {
+    for (int t = tid; t < S * CHK; t += nt) {
         const int kk = t / S, slot = t - kk * S, k = k0 + kk;
         if (kk >= kn) continue;
         const int tropo = sh.lay[k].idx >> 16;
@@ -844,8 +848,8 @@ struct GasLoads {
     bool two;
 };
 
-template <typename FT, bool SW>
-__device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb,
+template <typename FT, bool SW, int CHK>
+__device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, const ColShared<FT, CHK> &sh, const LaneBand &lb,
                                                       int k, int kk) {
     constexpr unsigned E = sizeof(FT), EK = SW ? E : 2 * E;  // LW: (kmajor, planck_fraction) pairs
     GasLoads<FT, SW> G;
@@ -980,8 +984,8 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
     (void)E;
 }
 
-template <typename FT, bool SW>
-__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT> &sh, const LaneBand &lb, int k, int kk,
+template <typename FT, bool SW, int CHK>
+__device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared<FT, CHK> &sh, const LaneBand &lb, int k, int kk,
                                            int nb, FT &tau, FT &ssa, FT &pfrac) {
     const GasLoads<FT, SW> G = gas_issue<FT, SW>(lk, sh, lb, k, kk);
     gas_finish<FT, SW>(lk, G, tau, ssa, pfrac);
@@ -989,8 +993,8 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
 
 // ---- McICA mask for this lane's g-point: cloud_optics.jl:264-334 ----------------------------
 // Bits of (m0, m1) are layers 0..63 / 64..127.  Returns any(mask).
-template <typename FT>
-__device__ inline bool build_cloud_mask(const ColShared<FT> &sh, const ColDims &d, uint64_t key, uint64_t &m0,
+template <typename FT, int CHK>
+__device__ inline bool build_cloud_mask(const ColShared<FT, CHK> &sh, const ColDims &d, uint64_t key, uint64_t &m0,
                                         uint64_t &m1) {
     m0 = m1 = 0;
     const int start = sh.misc[d.nwaves + 1], finish = sh.misc[d.nwaves + 2];
@@ -1056,8 +1060,8 @@ struct MaskWalk {
 // counter: columns differ in cost (cloudy layers, minor-gas counts across the tropopause), and with a static
 // stride the launch ends when the unluckiest workgroup does.  Which workgroup solves a column does not enter the
 // result (per-workgroup scratch, McICA keyed by the global column).
-template <typename FT>
-__device__ __forceinline__ int next_column(const ColShared<FT> &sh, const ColDims &d, int *queue) {
+template <typename FT, int CHK>
+__device__ __forceinline__ int next_column(const ColShared<FT, CHK> &sh, const ColDims &d, int *queue) {
     __syncthreads();
     if (threadIdx.x == 0) sh.misc[d.nwaves + 3] = (int)gridDim.x + atomicAdd(queue, 1);
     __syncthreads();
@@ -1066,11 +1070,12 @@ __device__ __forceinline__ int next_column(const ColShared<FT> &sh, const ColDim
 
 // ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
 // recurrences are carried next to the all-sky ones) ----------------------------------------
+constexpr int SWEEP_LANES = 256;  // lanes per scratch row, whatever the workgroup size (<= 256 g-points per lookup)
 template <typename FT, int NV = 3>
 struct Sweep {
     char *base;     // this workgroup's slab (wave-uniform)
     unsigned lane;  // threadIdx.x * sizeof(FT)
-    unsigned row;   // blockDim.x * sizeof(FT)
+    static constexpr unsigned row = SWEEP_LANES * sizeof(FT);  // a compile-time stride: neighbouring rows are immediate offsets
     __device__ __forceinline__ FT *ptr(int lev, int a) const {
 #ifdef RR_EXP_SCRATCH_ROW0  // timing-only experiment: every access hits level 0's rows (same instructions, 1/nlev of the footprint)
         lev = 0;
@@ -1078,6 +1083,9 @@ struct Sweep {
         return reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
     }
     __device__ __forceinline__ void put(int lev, int a, FT v) const {
+#ifdef RR_EXP_SCRATCH_ROW0_STORES  // timing-only: the stores alone lose their footprint
+        lev = 0;
+#endif
 #ifdef RR_SCRATCH_NT_STORE
         __builtin_nontemporal_store(v, ptr(lev, a));
 #else
@@ -1085,6 +1093,9 @@ struct Sweep {
 #endif
     }
     __device__ __forceinline__ FT get(int lev, int a) const {
+#ifdef RR_EXP_SCRATCH_ROW0_LOADS  // timing-only: the loads alone lose their footprint
+        lev = 0;
+#endif
 #ifdef RR_SCRATCH_NT_LOAD
         return __builtin_nontemporal_load(ptr(lev, a));
 #else
@@ -1096,8 +1107,8 @@ struct Sweep {
 // ---- write one column's broadband fluxes ---------------------------------------------------
 // compute_net_flux! (Fluxes.jl:225-237) then apply_metric_scaling! (:295-304): net = up - dn first,
 // then up, dn, net (and dir) are each multiplied by the (nlev, ncol) factor.
-template <typename FT>
-__device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT> &sh, const ColDims &d, int col, int ncol,
+template <typename FT, int CHK>
+__device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT, CHK> &sh, const ColDims &d, int col, int ncol,
                                     bool zero, const DevGas<FT> &lk) {
     const int nlev = d.nlev;
     // accumulator components per level: all-sky (up, dn[, dir]) and, with the clear-sky diagnostic, the same again

@@ -86,8 +86,8 @@ struct LwArgs {
 };
 
 // cloud + aerosol increments of one layer for this lane (TwoStream), or their absorption only (OneScalar)
-template <typename FT, bool TWOSTREAM>
-__device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColShared<FT> &sh, const LaneBand &lb, int k,
+template <typename FT, bool TWOSTREAM, int CHK>
+__device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColShared<FT, CHK> &sh, const LaneBand &lb, int k,
                                                     int kk, bool cloudy, FT &tau, FT &ssa, FT &g) {
     g = FT(0);
     const int r = kk * NBMAX + lb.ibnd;
@@ -104,8 +104,8 @@ __device__ __forceinline__ void lw_layer_increments(const ColDims &d, const ColS
 }
 
 // optics of one layer for this lane: gas, then the increments
-template <typename FT, bool TWOSTREAM>
-__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColDims &d, const ColShared<FT> &sh,
+template <typename FT, bool TWOSTREAM, int CHK>
+__device__ __forceinline__ void lw_layer_optics(const LwArgs<FT> &a, const ColDims &d, const ColShared<FT, CHK> &sh,
                                                 const LaneBand &lb, int k, int kk, bool cloudy, FT &tau, FT &ssa,
                                                 FT &g, FT &pfrac) {
     gas_optics<FT, false>(a.lk, sh, lb, k, kk, d.nbnd, tau, ssa, pfrac);
@@ -122,7 +122,8 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    ColShared<FT> sh;
+    constexpr int CHK = chunk_layers(CA);  // layers per chunk of LDS records
+    ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
     dd.diag = DIAG;  // what the host set, as a constant: the other flux set's pointers are never loaded
@@ -137,10 +138,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 4 : 2;  // accumulated components per level: up, dn (+ clear up, dn)
-    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * blockDim.x), (unsigned)(tid * sizeof(FT)),
-                     (unsigned)(blockDim.x * sizeof(FT))};
+    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
-    const int nchunk = (nlay + CH - 1) / CH;
+    const int nchunk = (nlay + CHK - 1) / CHK;
     const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
 
     for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 }
             };
             for (int c = 0; c < nchunk; c++) {
-                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE  // timing-only experiment: chunk records prepared for the first chunk only (barriers kept)
                 if (c == 0)
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
             //      (longwave_noscat.jl:45-96, 224-301) ----
             FT inc_prev = FT(0);
             for (int c = 0; c < nchunk; c++) {
-                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
                 RR_CHUNK_SYNC();
@@ -448,8 +448,11 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     double Ds[4], wts[4];
     angular_discretization(a.n_angles, Ds, wts);
     for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
-    ColShared<FT> dummy;
-    const size_t lds = carve_shared(dummy, (char *)nullptr, d);
+    // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
+    const bool ca_aero = twostream && aero && (diag || !fl.band_up);
+    ColShared<FT, chunk_layers(0)> dummy;
+    ColShared<FT, chunk_layers(2)> dummy_aero;
+    const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
@@ -462,7 +465,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT);
+    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
     int rc = scratch_ensure(ws, sweep_bytes + 256);
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;

@@ -90,7 +90,8 @@ constexpr int DB = 16;  // levels per batch of the light sweeps
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    ColShared<FT> sh;
+    constexpr int CHK = chunk_layers(CA);  // layers per chunk of LDS records
+    ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
     dd.diag = DIAG;  // what the host set, as a constant: the other flux set's pointers are never loaded
@@ -105,11 +106,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 6 : 3;  // accumulated components per level: up, dn, dir (+ the clear-sky three)
-    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * blockDim.x), (unsigned)(tid * sizeof(FT)),
-                     (unsigned)(blockDim.x * sizeof(FT))};
+    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
-    const int nchunk = (nlay + CH - 1) / CH;
+    const int nchunk = (nlay + CHK - 1) / CHK;
     const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
     const bool want_aod = d.has_aero && a.aero.iband_550nm > 0 && a.as.aod_sw_ext != nullptr;
 
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 if (writer) { acc[nlay * 3] = FT(0); acc[nlay * 3 + 1] = s; acc[nlay * 3 + 2] = s; }
             }
             for (int c = nchunk - 1; c >= 0; c--) {
-                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
                 RR_CHUNK_SYNC();
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
                 t.dir_above = dir_k;
             };
             for (int c = nchunk - 1; c >= 0; c--) {
-                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE
                 if (c == nchunk - 1)
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
         } else if (want_aod) {
             // night column: the reference still runs the optics, so the AOD diagnostic is defined
             for (int c = 0; c < nchunk; c++) {
-                const int k0 = c * CH, kn = min(CH, nlay - k0);
+                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
             }
@@ -379,8 +379,11 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 6 : 3; d.diag = diag; d.max_int = max_int;
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
-    ColShared<FT> dummy;
-    const size_t lds = carve_shared(dummy, (char *)nullptr, d);
+    // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
+    const bool ca_aero = twostream && aero && (diag || !fl.band_up);
+    ColShared<FT, chunk_layers(0)> dummy;
+    ColShared<FT, chunk_layers(2)> dummy_aero;
+    const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
@@ -393,7 +396,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : aero ? sw_solve_kernel<FT, true, false, false, 2> : sw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * threads * sizeof(FT);
+    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
     int rc = scratch_ensure(ws, sweep_bytes + 256);
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
