@@ -914,9 +914,13 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         return Corners<FT>{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + NCb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + NCb, x2)};
     };
     const V4<FT> z4{FT(0), FT(0), FT(0), FT(0)};
+    // g1 / s1 stay unset unless the second group is loaded (gas_finish reads them under the same wave-uniform flag):
+    // zero-filling them costs 20 v_mov per layer, and invites the compiler to run the second group's 20 FMAs always
+    G.two = false;
+#if defined(RR_EXP_NO_MINOR) || defined(RR_EXP_ZERO_G1)
     G.g0 = G.g1 = Corners<FT>{z4, z4, z4, z4};
     G.s0 = G.s1 = z4;
-    G.two = false;
+#endif
 #ifndef RR_EXP_NO_MINOR
     G.g0 = corners(G.a1, G.a2);
     G.s0 = *reinterpret_cast<const V4<FT> *>(G.ms);
