@@ -181,3 +181,46 @@ def test_ccall_argument_counts_match_the_header():
             assert len(c_args) == len(types), (sym, len(c_args), len(types))
             n_checked += 1
     assert n_checked >= 18, n_checked
+
+
+# What the reference's constructors put into the fields that are typed by an unbounded type parameter
+# (AtmosphericStates.jl:70-81, LookUpTables.jl:123-147, 174-205): the chains the glue follows through them.
+FIELD_HINTS = {
+    ("AtmosphericState", "cloud_state"): ["CloudState"],
+    ("AtmosphericState", "aerosol_state"): ["AerosolState"],
+    ("AtmosphericState", "vmr"): ["Vmr", "VmrGM"],
+    ("LookUpLW", "planck"): ["LookUpPlanck"],
+    ("LookUpLW", "band_data"): ["BandData"], ("LookUpSW", "band_data"): ["BandData"],
+    ("LookUpLW", "ref_points"): ["ReferencePoints"], ("LookUpSW", "ref_points"): ["ReferencePoints"],
+    ("LookUpLW", "minor_lower"): ["LookUpMinor"], ("LookUpLW", "minor_upper"): ["LookUpMinor"],
+    ("LookUpSW", "minor_lower"): ["LookUpMinor"], ("LookUpSW", "minor_upper"): ["LookUpMinor"],
+}
+
+
+def _bad_fields(src):
+    structs = SIGS["structs"]
+    out = []
+    for m in JLITE.parse_module(src).methods:
+        out += [(m.name, chain, why) for chain, why, _ in JLITE.bad_field_accesses(m, structs, FIELD_HINTS)]
+    return out
+
+
+def test_every_field_access_names_a_field_of_the_reference_struct():
+    """`as.layerdata`, `lkp.planck.tot_planck`, `cs.cld_frac` ...: every chain whose base is a parameter typed with a
+    reference struct (or a local bound to such a chain) is followed through the reference's struct definitions
+    (golden: names and annotations extracted by tools/julia_signatures.py).  A union-typed parameter must have the
+    field in every member."""
+    structs = SIGS["structs"]
+    assert len(structs) >= 40 and [f for f, _ in structs["AtmosphericState"]["fields"]][:3] == ["lon", "lat", "layerdata"]
+    mod = _module()
+    typed = sum(1 for m in mod.methods for p in m.params if p.type and JLITE._type_structs(p.type, structs))
+    assert typed >= 40, typed  # the check is not vacuous: that many parameters carry a reference struct type
+    assert _bad_fields(JL) == []
+
+
+def test_field_checker_catches_a_wrong_field_name():
+    broken = JL.replace("ptr(cs.cld_frac)", "ptr(cs.cloud_frac)", 1)
+    assert broken != JL
+    assert ("state_desc", "cs.cloud_frac", "CloudState has no field cloud_frac") in _bad_fields(broken)
+    broken = JL.replace("as.t_sfc", "as.t_surface", 1)
+    assert any(why.endswith("has no field t_surface") for _, _, why in _bad_fields(broken))

@@ -523,3 +523,74 @@ def unresolved_names(m: Method, module_names: set, extra: set = frozenset()) -> 
 
 def norm_type(t: str) -> str:
     return re.sub(r"\s+", "", t)
+
+
+# ---------------------------------------------------------------------------- field accesses
+def _type_structs(type_text: str, structs: dict) -> set:
+    """Struct names mentioned by a type annotation (`Union{LookUpLW{FT}, LookUpSW{FT}}`, `RRTMGP.Fluxes.FluxLW`)."""
+    return {t.text for t in tokenize(type_text) if t.kind == "id" and t.text in structs}
+
+
+def bad_field_accesses(m: Method, structs: dict, hints: dict) -> List[Tuple[str, str, int]]:
+    """`x.f` / `x.f.g` chains in a method body whose base is a parameter (or a local assigned from such a chain) with a
+    known struct type, naming a field the struct does not have.  `structs` = {name: {"fields": [[name, type]], ...}},
+    `hints` = {(struct, field): [struct names]} for fields typed by an unbounded type parameter.
+    A union type must have the field in every member.  Returns (chain text, problem, line)."""
+    env = {}
+    for p in list(m.params) + list(m.kwparams):
+        if p.name and p.type:
+            ts = _type_structs(p.type, structs)
+            if ts:
+                env[p.name] = ts
+
+    def field_types(owner: str, fld: str):
+        decl = dict((f, t) for f, t in structs[owner]["fields"]).get(fld)
+        if decl is None:
+            return None
+        if (owner, fld) in hints:
+            return set(hints[(owner, fld)])
+        ts = _type_structs(decl, structs)
+        if not ts:  # a type parameter: its bound may name a struct
+            ts = _type_structs(structs[owner]["params"].get(decl, ""), structs)
+        return ts
+
+    bad, toks, i = [], [t for t in m.body if t.kind != "nl" or True], 0
+    while i < len(toks):
+        t = toks[i]
+        prev = toks[i - 1] if i else None
+        if t.kind == "id" and t.text in env and not (prev and prev.kind == "op" and prev.text == "."):
+            cur, chain, j = set(env[t.text]), t.text, i
+            while j + 2 < len(toks) and toks[j + 1].kind == "op" and toks[j + 1].text == "." and toks[j + 2].kind == "id":
+                fld = toks[j + 2].text
+                chain += "." + fld
+                nxt = set()
+                for owner in cur:
+                    ft = field_types(owner, fld)
+                    if ft is None:
+                        bad.append((chain, f"{owner} has no field {fld}", toks[j + 2].line))
+                    else:
+                        nxt |= ft
+                cur, j = nxt, j + 2
+                if not cur:
+                    # unknown type from here on: skip the rest of the chain
+                    while j + 2 < len(toks) and toks[j + 1].kind == "op" and toks[j + 1].text == "." and toks[j + 2].kind == "id":
+                        j += 2
+                    break
+            # `local = chain` and `local = cond ? chain : nothing` (a statement without calls) bind the local to the
+            # chain's type
+            a = i
+            while a > 0 and toks[a - 1].kind != "nl":
+                a -= 1
+            b = j + 1
+            while b < len(toks) and toks[b].kind != "nl":
+                b += 1
+            if a + 1 < i and toks[a].kind == "id" and toks[a + 1].kind == "op" and toks[a + 1].text == "=" and \
+                    not any(x.text in "([{" for x in toks[a:i] + toks[j + 1:b]):
+                if cur:
+                    env[toks[a].text] = cur
+                else:
+                    env.pop(toks[a].text, None)
+            i = j + 1
+            continue
+        i += 1
+    return bad
