@@ -224,3 +224,35 @@ def test_field_checker_catches_a_wrong_field_name():
     assert ("state_desc", "cs.cloud_frac", "CloudState has no field cloud_frac") in _bad_fields(broken)
     broken = JL.replace("as.t_sfc", "as.t_surface", 1)
     assert any(why.endswith("has no field t_surface") for _, _, why in _bad_fields(broken))
+
+
+def test_every_imported_and_qualified_reference_name_exists():
+    """`import RRTMGP.Optics: compute_col_gas!`, `RP.grav(ps)`, `RRTMGP.RTE._default_state_cache(...)`: each name the
+    glue takes from RRTMGP is defined in that module of the reference (golden index of names per module, built by
+    tools/julia_signatures.py along the reference's include tree)."""
+    mods = SIGS["modules"]
+    assert {"RRTMGP", "RRTMGP.Optics", "RRTMGP.RTE", "RRTMGP.RTESolver", "RRTMGP.Parameters"} <= set(mods)
+    code = "\n".join(l.split("#")[0] for l in JL.split("\n"))
+    aliases, checked, missing = {}, 0, []
+    for m in re.finditer(r"^import (RRTMGP(?:\.\w+)*) as (\w+)$", code, re.M):
+        aliases[m.group(2)] = m.group(1)
+    for m in re.finditer(r"^import (RRTMGP(?:\.\w+)*):((?:[^\n]|\n {4})*)", code, re.M):
+        for nm in re.findall(r"[\w!]+", m.group(2)):
+            checked += 1
+            if nm not in mods.get(m.group(1), ()):
+                missing.append(f"{m.group(1)}: {nm}")
+    # qualified uses: RRTMGP.<Module>.<name>, RRTMGP.<name>, <alias>.<name>
+    for m in re.finditer(r"\b(RRTMGP(?:\.[A-Z]\w*)*)\.([a-z_][\w!]*|[A-Z]\w*)\b", code):
+        owner, nm = m.group(1), m.group(2)
+        if owner + "." + nm in mods:   # a module path, not a name
+            continue
+        checked += 1
+        if nm not in mods.get(owner, ()):
+            missing.append(f"{owner}.{nm}")
+    for al, owner in aliases.items():
+        for m in re.finditer(r"\b" + al + r"\.([\w!]+)", code):
+            checked += 1
+            if m.group(1) not in mods[owner]:
+                missing.append(f"{owner}.{m.group(1)}")
+    assert checked >= 40, checked
+    assert missing == []

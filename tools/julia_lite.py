@@ -372,6 +372,9 @@ def parse_module(src: str) -> Module:
             i = j; continue
         if t.kind == "id" and t.text == "function":
             e = _block_end(toks, i)
+            if e == i + 2 and toks[i + 1].kind == "id":   # `function name end`: a declaration without methods
+                mod.methods.append(Method(toks[i + 1].text, [], [], [], [], t.line, False))
+                i = e + 1; continue
             name, pos, kw, where, after = _parse_signature(toks, i + 1)
             mod.methods.append(Method(name, pos, kw, where, toks[after:e], t.line, False))
             i = e + 1; continue
