@@ -203,8 +203,9 @@ typedef struct rrtmgp_flux_out {
      * g-point into the g-point's band and metric-scaled as RTESolver.jl:141,246 does;
      * `band_flux_net` (may be NULL on its own) = scaled up - scaled dn, which the reference
      * fills one step later in update_net_fluxes! (src/api/update_fluxes.jl:198-201).
-     * This back end requires every band to span whole 16-g-point groups (true of
-     * rrtmgp-data v1.9) and answers RRTMGP_EUNSUPPORTED otherwise. */
+     * The per-band kernels lay the g-points out band by band on 16-lane rows: any band structure
+     * whose bands, each rounded up to 16 g-points, fit 256 lanes (rrtmgp-data v1.9 g256 / g224 and
+     * the reduced g128 / g112 sets do); RRTMGP_EUNSUPPORTED otherwise. */
     void *band_flux_up;
     void *band_flux_dn;
     void *band_flux_net;

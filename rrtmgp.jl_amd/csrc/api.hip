@@ -229,9 +229,15 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         if (lo[b] < 0) lo[b] = (int)i;
         ng[b]++;
     }
-    g.band16 = 1;
-    for (int64_t b = 0; b < NB; b++)
-        if (ng[b] == 0 || (lo[b] & 15) || (ng[b] & 15)) g.band16 = 0;
+    // lane layout of the per-band flux variants (common.h): band by band on 16-lane rows
+    std::vector<int> row_lo(NB + 1, 0), lane_gpt(256, -1);
+    for (int64_t b = 0; b < NB; b++) row_lo[b + 1] = row_lo[b] + (ng[b] + 15) / 16;
+    g.band_rows = row_lo[NB] <= 16 ? row_lo[NB] : 0;
+    if (g.band_rows)
+        for (int64_t b = 0; b < NB; b++)
+            for (int i = 0; i < ng[b]; i++) lane_gpt[row_lo[b] * 16 + i] = lo[b] + i;
+    TRY(upload(lk, row_lo, &g.band_row_lo));
+    TRY(upload(lk, lane_gpt, &g.band_lane_gpt));
     TRY(upload(lk, ks, &g.key_species));
     TRY(upload(lk, g2b, &g.gpt2bnd));
     TRY(upload(lk, lo, &g.bnd_lo));

@@ -24,7 +24,12 @@ namespace rrtmgp {
 template <typename FT>
 struct DevGas {
     int is_sw, n_gpt, n_bnd, n_eta, n_pp /* n_p_ref + 1 */, n_t_ref, n_gases, n_t_plnk, idx_h2o;
-    int band16;  // every band starts on, and spans a multiple of, 16 g-points (one DPP row): per-band fluxes possible
+    // per-band fluxes: the lanes of a workgroup are laid out band by band, every band starting on a 16-lane DPP row
+    // (padding lanes idle); band_rows = rows of that layout, 0 when it needs more than the 16 rows of a workgroup.
+    // With whole 16-g-point bands (rrtmgp-data g256 / g224) the layout is the identity.
+    int band_rows;
+    const int *band_row_lo;    // [n_bnd + 1] first row of each band
+    const int *band_lane_gpt;  // [256] g-point (0-based) of each lane of that layout, -1 for padding
     FT p_ref_tropo;
     // the tables the g-point lanes gather from live in ONE allocation (one scalar base address for
     // every global_load of the hot loop); offsets in bytes:

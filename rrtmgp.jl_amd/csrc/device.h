@@ -1140,14 +1140,14 @@ __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT, C
             if (ncomp == 3 && fl.clear_dir) fl.clear_dir[o] = dir;
         }
     }
-    // FluxBand (Fluxes.jl:170-215): band b owns the rows [bnd_lo/16, (bnd_lo + bnd_ng)/16); scaled like
+    // FluxBand (Fluxes.jl:170-215): band b owns the rows [band_row_lo[b], band_row_lo[b + 1]); scaled like
     // the broadband fluxes (Fluxes.jl:448-454), net from the scaled values (update_fluxes.jl:198-201)
     if (fl.band_up) {
         for (int i = threadIdx.x; i < d.nbnd * nlev; i += blockDim.x) {
             const int b = i / nlev, lev = i - b * nlev;
             FT up = FT(0), dn = FT(0);
             if (!zero) {
-                const int r0 = lk.bnd_lo[b] >> 4, r1 = (lk.bnd_lo[b] + lk.bnd_ng[b]) >> 4;
+                const int r0 = lk.band_row_lo[b], r1 = lk.band_row_lo[b + 1];
                 for (int r = r0; r < r1; r++) {
                     up += sh.acc[((size_t)r * nlev + lev) * d.n_acc];
                     dn += sh.acc[((size_t)r * nlev + lev) * d.n_acc + 1];

@@ -133,8 +133,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const bool active = tid < a.lk.n_gpt;
-    const int g = active ? tid : a.lk.n_gpt - 1;
+    // lane -> g-point: the identity, or (per-band fluxes) the band-by-band layout on 16-lane rows
+    const int gl = BAND ? a.lk.band_lane_gpt[tid] : (tid < a.lk.n_gpt ? tid : -1);
+    const bool active = gl >= 0;
+    const int g = active ? gl : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 4 : 2;  // accumulated components per level: up, dn (+ clear up, dn)
@@ -426,13 +428,13 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     if (aero) a.aero = *aero;
     a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux;
     a.seed = seed; a.col_offset = col_offset;
-    const int threads = ((lk.n_gpt + 63) / 64) * 64;
+    const int threads = ((fl.band_up ? lk.band_rows * 16 : lk.n_gpt) + 63) / 64 * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     RR_CHECK(lk.n_eta <= 255 && lk.n_pp <= 255 && lk.n_t_ref <= 255, "lookup axes longer than 255 are not supported");
     RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
     if (fl.band_up) {
         RR_CHECK(twostream && fl.band_dn, "per-band fluxes need a two-stream solver and both up/dn buffers");
-        if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
+        if (!lk.band_rows) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes: the bands, each padded to 16 g-points, must fit 256 lanes");
     }
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;

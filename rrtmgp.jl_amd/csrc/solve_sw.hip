@@ -101,8 +101,10 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAV
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const bool active = tid < a.lk.n_gpt;
-    const int g = active ? tid : a.lk.n_gpt - 1;
+    // lane -> g-point: the identity, or (per-band fluxes) the band-by-band layout on 16-lane rows
+    const int gl = BAND ? a.lk.band_lane_gpt[tid] : (tid < a.lk.n_gpt ? tid : -1);
+    const bool active = gl >= 0;
+    const int g = active ? gl : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 6 : 3;  // accumulated components per level: up, dn, dir (+ the clear-sky three)
@@ -361,7 +363,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     a.as = as; a.fl = fl;
     a.cos_zenith = cos_zenith; a.toa_flux = toa_flux; a.alb_dir = alb_dir; a.alb_dif = alb_dif;
     a.seed = seed; a.col_offset = col_offset;
-    const int threads = ((lk.n_gpt + 63) / 64) * 64;
+    const int threads = ((fl.band_up ? lk.band_rows * 16 : lk.n_gpt) + 63) / 64 * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
     ColDims d{};
     d.nlay = as.nlay; d.nlev = as.nlay + 1;
@@ -370,7 +372,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     RR_CHECK(lk.n_bnd <= NBMAX, "more than 16 bands per lookup are not supported");
     if (fl.band_up) {
         RR_CHECK(twostream && fl.band_dn, "per-band fluxes need a two-stream solver and both up/dn buffers");
-        if (!lk.band16) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes need bands made of whole 16-g-point groups");
+        if (!lk.band_rows) return rrtmgp::set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes: the bands, each padded to 16 g-points, must fit 256 lanes");
     }
     d.nwaves = threads / 64; d.nseg = fl.band_up ? threads / 16 : d.nwaves;
     d.n_t_ref = lk.n_t_ref; d.n_p_ref = lk.n_pp - 1; d.n_t_plnk = lk.n_t_plnk; d.n_gases_ref = lk.n_gases;

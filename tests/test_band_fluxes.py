@@ -2,7 +2,7 @@
 src/api/getters.jl:398-470).  CPU: the oracle's band buffers against an independent
 g-point-by-g-point numpy restatement and the sum-over-bands identity.  GPU: HIP parity with
 the oracle through the C ABI, metric scaling, night columns, the L2 getters, and the
-documented limit (bands made of whole 16-g-point groups)."""
+ragged bands (not whole 16-g-point groups) and the one remaining limit (padded bands must fit 256 lanes)."""
 import numpy as np
 import pytest
 
@@ -83,16 +83,66 @@ def test_hip_band_fluxes_match_oracle(tables64, FT, tol_lw, tol_sw):
             assert night.any() and not np.asarray(slv.band_flux.flux_up)[:, night].any()
 
 
+def _band_parity(t, FT, tol_lw, tol_sw, **case_kw):
+    from rrtmgp_jl_amd import rte
+    t64 = t
+    tF = {k: v.astype(FT) for k, v in t64.items()}
+    as64, lb64, sb64, m64 = _case(t64, **case_kw)
+    as_, lb, sb, metric = _case(tF, FT, **case_kw)
+    for sw in (False, True):
+        r = "sw" if sw else "lw"
+        aero = case_kw.get("aerosols", False)
+        cl = case_kw.get("clouds", True)
+        lk, cld, ae = tF[r], tF["cld_" + r] if cl else None, tF["aero_" + r] if aero else None
+        lk64, cld64, ae64 = t64[r], t64["cld_" + r] if cl else None, t64["aero_" + r] if aero else None
+        ref_b = FluxBand.allocate(NCOL, NLAY + 1, lk.n_bnd, np.float64)
+        ref = (oracle.solve_sw if sw else oracle.solve_lw)(as64, sb64 if sw else lb64, lk64, cld64, ae64,
+                                                           band_flux=ref_b, metric_scaling=m64, seed=5)
+        cls = rte.TwoStreamSWRTE if sw else rte.TwoStreamLWRTE
+        slv = cls(NCOL, NLAY, FT, sb if sw else lb, n_bnd_band_flux=lk.n_bnd)
+        f = (rte.solve_sw if sw else rte.solve_lw)(slv, as_, lk, cld, ae, metric_scaling=metric, seed=5)
+        tol = tol_sw if sw else tol_lw
+        for n in ("flux_up", "flux_dn", "flux_net"):
+            got = np.asarray(getattr(slv.band_flux, n), dtype=np.float64)
+            assert np.abs(got - getattr(ref_b, n)).max() <= tol, (sw, n)
+            assert np.abs(np.asarray(getattr(f, n), dtype=np.float64) - getattr(ref, n)).max() <= tol, (sw, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("FT,tol_lw,tol_sw", [(np.float64, 1e-10, 1e-10), (np.float32, 2e-3, 3e-2)])
+def test_hip_band_fluxes_ragged_bands(small_tables64, FT, tol_lw, tol_sw):
+    """Bands that are not whole 16-g-point groups (8/4/12 and 6/10/4): the per-band variants lay the lanes out band
+    by band on 16-lane rows, padding lanes idle."""
+    _band_parity(small_tables64, FT, tol_lw, tol_sw, aerosols=True)
+
+
+@pytest.mark.gpu
+def test_hip_band_fluxes_reduced_gpoint_sets():
+    """The shape of rrtmgp-data's reduced sets (rrtmgp-gas-lw-g128 / sw-g112: 16 / 14 bands of 4-12 g-points)."""
+    rng = np.random.default_rng(11)
+    n_lw, n_sw = 16, 14
+    g_lw = rng.integers(4, 13, n_lw)
+    g_sw = rng.integers(4, 13, n_sw)
+    lw = S.make_gas_lookup("lw", np.float64, seed=3, gpt_per_bnd=[int(x) for x in g_lw])
+    sw = S.make_gas_lookup("sw", np.float64, seed=3, gpt_per_bnd=[int(x) for x in g_sw])
+    t = dict(lw=lw, sw=sw, cld_lw=S.make_cloud_lookup("lw", n_lw, seed=3), cld_sw=S.make_cloud_lookup("sw", n_sw, seed=3))
+    _band_parity(t, np.float64, 1e-10, 1e-10)
+
+
 @pytest.mark.gpu
 def test_hip_band_fluxes_limits_and_device_memory(tables64, small_tables64):
     import torch
     from rrtmgp_jl_amd import rte, _lib
-    # ragged bands (8/4/12 g-points): documented limit, loud error, broadband still fine
-    t = small_tables64
-    as_, lb, sb, _ = _case(t, clouds=False)
-    slv = rte.TwoStreamLWRTE(NCOL, NLAY, np.float64, lb, n_bnd_band_flux=t["lw"].n_bnd)
-    with pytest.raises(_lib.RRTMGPHipError, match="16-g-point"):
-        rte.solve_lw(slv, as_, t["lw"])
+    # the one remaining limit: the bands, each padded to whole 16-lane rows, must fit the 256 lanes of a workgroup
+    # (9 bands of 17 g-points need 18 rows); loud error, and the broadband solve of the same lookup is fine
+    lw = S.make_gas_lookup("lw", np.float64, seed=5, n_bnd=9, gpt_per_bnd=17)
+    as_, lb, sb = S.make_columns(NCOL, NLAY, np.float64, seed=23, n_bnd_lw=9, n_bnd_sw=3, clouds=False)
+    slv = rte.TwoStreamLWRTE(NCOL, NLAY, np.float64, lb, n_bnd_band_flux=9)
+    with pytest.raises(_lib.RRTMGPHipError, match="256 lanes"):
+        rte.solve_lw(slv, as_, lw)
+    f = rte.solve_lw(rte.TwoStreamLWRTE(NCOL, NLAY, np.float64, lb), as_, lw)
+    ref = oracle.solve_lw(as_, lb, lw)
+    assert np.abs(np.asarray(f.flux_up) - ref.flux_up).max() <= 1e-10
     with pytest.raises(ValueError, match="two-stream"):
         rte.NoScatLWRTE(NCOL, NLAY, np.float64, lb, n_bnd_band_flux=3)
     # device-resident band buffers (torch tensors), same numbers as host-staged
