@@ -72,6 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--shards", type=int, default=0,
                     help="with --host: ONE process drives this many column shards through a multi-device workspace "
                          "(rrtmgp_hip_workspace_create_multi): device ids 0..n-1, wrapped onto the visible GPUs")
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N: ONE host process (no torch.distributed) hands host arrays of N x --ncol columns "
+                         "to a multi-device workspace over GPUs 0..N-1; the library fans out (one host thread + stream "
+                         "per GPU) and returns when every slab is home.  What a Julia host gets from HIPDevice(ids)")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1: LW and SW kernels on torch's current stream; 2: each on its own stream (concurrent)")
     ap.add_argument("--clear-sky-diag", choices=["off", "one-pass", "two-solves"], default="off",
@@ -108,7 +112,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
+    single = args.single_process
+    if single:
+        if world != 1:
+            raise SystemExit("--single-process is one process: do not launch it through torch.distributed.run")
+        args.host, args.shards = True, args.gpus
+    elif args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
     _lib.require_gpu()
@@ -128,7 +137,7 @@ def main():
             dist.init_process_group(backend)
 
     ft = np.float32 if args.dtype == "f32" else np.float64
-    ncol0, nlay = args.ncol, args.nlay
+    ncol0, nlay = args.ncol * (args.gpus if single else 1), args.nlay
     ncol = ncol0 * args.tile
     lw, sw = S.make_gas_lookup("lw", ft), S.make_gas_lookup("sw", ft)
     cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)
@@ -232,7 +241,8 @@ def main():
     assert bool(torch.isfinite(sdn).all())
 
     if rank == 0:
-        value = world * ncol * args.steps / elapsed
+        value = world * ncol * args.steps / elapsed   # single-process: ncol already is the whole job
+        n_gpus = args.gpus if single else world
         step_ms = None
         if per_step:
             step_ms = {"min": min(per_step), "median": statistics.median(per_step), "mean": statistics.fmean(per_step),
@@ -277,18 +287,20 @@ def main():
             "metric": "columns/sec, all-sky LW+SW 2-stream (nlay=64, 256+224 gpt)",
             "value": value,
             "unit": "columns/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"all-sky (McICA clouds, cld_frac={args.cld_frac:g}) LW+SW two-stream, "
-                                   f"{ncol} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
+                                   f"{ncol // (args.gpus if single else 1)} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
                                    f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, "
                                    f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}"
                                    + (f", {len(shards)} shards in one process" if shards else "")
                                    + ("" if args.clear_sky_diag == "off" else f", + clear-sky diagnostic ({args.clear_sky_diag})"),
-                       "ncol_per_gpu": ncol, "nlay": nlay, "ngpt_lw": lw.n_gpt, "ngpt_sw": sw.n_gpt,
-                       "parallelism": f"columns sharded over {world} GPU(s), no collective"},
+                       "ncol_per_gpu": ncol // (args.gpus if single else 1), "nlay": nlay, "ngpt_lw": lw.n_gpt, "ngpt_sw": sw.n_gpt,
+                       "parallelism": (f"ONE host process, columns sharded over {n_gpus} GPU(s) inside the library "
+                                       "(rrtmgp_hip_workspace_create_multi), no collective" if single else
+                                       f"columns sharded over {world} GPU(s), no collective")},
             "step_ms": step_ms,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

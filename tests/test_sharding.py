@@ -110,3 +110,22 @@ def test_bench_multi_process_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "columns/s" and d["steps"] == 2
     assert d["config"]["ncol_per_gpu"] == 4096
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_single_process_fan_out_on_one_gpu():
+    """`bench.py --gpus 2 --single-process`: ONE process, host arrays of 2 x ncol columns, the library's multi-device
+    workspace fans out (device ids wrap onto the only GPU of the test box).  What a Julia host gets from
+    HIPDevice([0, 1])."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--steps", "2",
+                        "--warmup", "1", "--ncol", "4096", "--cpu-sample", "0", "--no-legs"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["ncol_per_gpu"] == 4096 and "ONE host process" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
