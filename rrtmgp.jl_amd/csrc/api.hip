@@ -367,6 +367,8 @@ struct Stager {
     std::vector<Back> backs;
     hipStream_t cs = nullptr;  // stream of the copies; the workspace stream unless the pipelined host path says otherwise
     bool pin_only = false;     // registration pass over the caller's WHOLE host arrays: no copies, no device memory
+    uint64_t keep = 0;         // pipelined host path, bit per slot: the array does not depend on the column range and an
+                               // earlier chunk has already put it into this staging set
     hipStream_t copy_stream() const { return cs ? cs : ws->stream; }
     bool pin(int mem, const void *p, size_t bytes, void **out) {
         if (!pin_only) return false;
@@ -381,7 +383,7 @@ struct Stager {
         if (pin(mem, p, bytes, const_cast<void **>(out))) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *out = p; return RRTMGP_OK; }
         TRY(stage_ensure(ws, slot, bytes));
-        RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
+        if (!((keep >> slot) & 1)) RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
     }
@@ -699,6 +701,12 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
         std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
         Stager st{ws, {}};
         st.cs = ws->copy_stream;
+        // the well-mixed vmr vector (VmrGM) does not depend on the column range: chunks 0 and 1 put it into the two
+        // staging sets, later chunks leave it there.  A copy that small is done by a blit KERNEL, which has to wait
+        // for a workgroup slot of the persistent solve grid (0.3 ms per chunk in the copy queue: rocprofv3 timeline,
+        // tools/experiments/host_timeline.sh)
+        static const bool restage_all = getenv("RRTMGP_HIP_HOST_RESTAGE_ALL") != nullptr;
+        if (!restage_all && c >= 2 && a.vmr_kind == RRTMGP_VMR_GM) st.keep |= 1ull << S_VMR;
         rc = solve_chunk(a, f, o, sl, st);
         if (rc == RRTMGP_OK && hipEventRecord(ws->ev_k[c & 1], ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipEventRecord");
         // chunk c - 1: its kernel is older than chunk c's, wait for it on the copy stream and bring the fluxes home
