@@ -27,7 +27,12 @@ constexpr int CH = 16;  // layers per preparation chunk
 // ... of the kernel variant CA (clouds | aerosols << 1, -1 = run-time flags): the aerosol records would push the LDS
 // of a workgroup past a quarter of the CU's 160 KB (3 resident workgroups instead of 4), so those variants prepare
 // 8 layers at a time
-__host__ __device__ constexpr int chunk_layers(int ca) { return ca >= 2 ? CH / 2 : CH; }
+#ifndef RR_DIAG_MIN_WAVES  // resident waves per SIMD the Float32 clear-sky-diagnostic variants are compiled for
+#define RR_DIAG_MIN_WAVES 3
+#endif
+__host__ __device__ constexpr int chunk_layers(int ca, bool diag = false) {
+    return ca >= 2 || (diag && RR_DIAG_MIN_WAVES >= 4) ? CH / 2 : CH;
+}
 
 #ifndef RR_MIN_WAVES
 #define RR_MIN_WAVES 4  // waves per SIMD the column kernels are register-allocated for

@@ -120,9 +120,9 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // CA: -1 = clouds / aerosols are run-time flags; 0..3 = (clouds | aerosols << 1) known at compile time (the main
 // two-stream instance: absent optics leave no code, no kernel arguments in registers and no lane masks behind).
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = chunk_layers(CA);  // layers per chunk of LDS records
+    constexpr int CHK = chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -451,7 +451,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     angular_discretization(a.n_angles, Ds, wts);
     for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
     // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
-    const bool ca_aero = twostream && aero && (diag || !fl.band_up);
+    const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));
     ColShared<FT, chunk_layers(0)> dummy;
     ColShared<FT, chunk_layers(2)> dummy_aero;
     const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);

@@ -88,9 +88,9 @@ constexpr int DB = 16;  // levels per batch of the light sweeps
 // DIAG: clear-sky recurrences carried next to the all-sky ones (see lw_solve_kernel)
 // CA: see lw_solve_kernel
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? 3 : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = chunk_layers(CA);  // layers per chunk of LDS records
+    constexpr int CHK = chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -382,7 +382,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
-    const bool ca_aero = twostream && aero && (diag || !fl.band_up);
+    const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));
     ColShared<FT, chunk_layers(0)> dummy;
     ColShared<FT, chunk_layers(2)> dummy_aero;
     const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
