@@ -173,7 +173,10 @@ typedef struct rrtmgp_atmos_state {
 /* LwBCs, src/optics/BCs.jl:17-26 */
 typedef struct rrtmgp_lw_bcs {
     int32_t mem;
-    int32_t _pad;
+    int32_t inc_flux_ld;  /* leading dimension of inc_flux: elements between consecutive g-points; 0 = ncol.  Larger
+                           * values describe a block of columns inside a wider (ncol_total, ngpt) array: that is how the
+                           * library itself hands column ranges of inc_flux (the one array whose FASTEST dimension is
+                           * ncol) to shards and pipeline chunks. */
     const void *sfc_emis; /* FT (nbnd_lw, ncol) */
     const void *inc_flux; /* FT (ncol, ngpt) or NULL */
 } rrtmgp_lw_bcs;
@@ -416,9 +419,9 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void
  *    shard so that the McICA stream stays keyed by the global column, and returns when every
  *    shard's results are in the caller's arrays.  The bits are those of a single launch.
  *  - Arrays must be host memory (RRTMGP_MEM_HOST) unless every shard is on the same device
- *    as the pointers.  Not shardable in one call, rejected with RRTMGP_EUNSUPPORTED when
- *    ndev > 1: flux layout RRTMGP_LAYOUT_NCOL_NLEV, LwBCs.inc_flux (both have ncol as the
- *    FASTEST dimension) and per-band fluxes.
+ *    as the pointers.  LwBCs.inc_flux, whose FASTEST dimension is ncol, is handed to the shards as
+ *    2-D blocks (inc_flux_ld).  Not shardable in one call, rejected with RRTMGP_EUNSUPPORTED when
+ *    ndev > 1: flux layout RRTMGP_LAYOUT_NCOL_NLEV (ncol fastest) and per-band fluxes.
  *  - Host arrays are page-locked on first use (hipHostRegister, cached per workspace by
  *    address and size, released by workspace_destroy) so that the per-shard uploads and
  *    downloads are true asynchronous DMA; RRTMGP_HIP_NO_HOST_REGISTER=1 turns this off.

@@ -58,7 +58,7 @@ class AtmosState(C.Structure):
 
 
 class LwBcs(C.Structure):
-    _fields_ = [("mem", i32), ("_pad", i32), ("sfc_emis", vp), ("inc_flux", vp)]
+    _fields_ = [("mem", i32), ("inc_flux_ld", i32), ("sfc_emis", vp), ("inc_flux", vp)]
 
 
 class SwBcs(C.Structure):

@@ -387,6 +387,14 @@ struct Stager {
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
     }
+    // input, HOST memory only: `height` rows of `width` bytes, `spitch` bytes apart at the source, packed in the staging buffer
+    int in2d(int slot, const void *p, size_t width, size_t height, size_t spitch, const void **out) {
+        if (pin_only) { *out = nullptr; return RRTMGP_OK; }  // the registration pass sees whole arrays (in())
+        TRY(stage_ensure(ws, slot, width * height));
+        RR_HIP(hipMemcpy2DAsync(ws->stage[slot].ptr, width, p, spitch, width, height, hipMemcpyHostToDevice, copy_stream()));
+        *out = ws->stage[slot].ptr;
+        return RRTMGP_OK;
+    }
     // output: returns device pointer; host copies are done by finish()
     int out(int mem, int slot, void *p, size_t bytes, void **outp) {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
@@ -540,7 +548,16 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     TRY(stage_state(st, as, cld != nullptr, aero != nullptr, true, ds, cld ? cld->nrghice : 1));
     const FT *emis, *inc;
     TRY(st.in(bcs->mem, S_BC0, bcs->sfc_emis, (size_t)lk.n_bnd * as->ncol * sizeof(FT), (const void **)&emis));
-    TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
+    // inc_flux is the one array whose fastest dimension is ncol: a column range of it is a 2-D block
+    const size_t inc_ld_in = bcs->inc_flux_ld > 0 ? (size_t)bcs->inc_flux_ld : (size_t)as->ncol;
+    RR_CHECK(!bcs->inc_flux || inc_ld_in >= (size_t)as->ncol, "LwBCs.inc_flux_ld is smaller than ncol");
+    int inc_ld = (int)as->ncol;  // what the kernel sees: host blocks are compacted while they are staged
+    if (bcs->inc_flux && inc_ld_in != (size_t)as->ncol && bcs->mem == RRTMGP_MEM_HOST) {
+        TRY(st.in2d(S_BC1, bcs->inc_flux, (size_t)as->ncol * sizeof(FT), (size_t)lk.n_gpt, inc_ld_in * sizeof(FT), (const void **)&inc));
+    } else {
+        if (bcs->inc_flux && bcs->mem == RRTMGP_MEM_DEVICE) inc_ld = (int)inc_ld_in;
+        TRY(st.in(bcs->mem, S_BC1, bcs->inc_flux, (size_t)lk.n_gpt * as->ncol * sizeof(FT), (const void **)&inc));
+    }
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl, twostream ? (size_t)lk.n_bnd : 0));
     if (st.pin_only) return RRTMGP_OK;
@@ -548,7 +565,7 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
         RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
     }
-    TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, fl, n_angles, opts ? opts->seed : 0,
+    TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, inc_ld, fl, n_angles, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
     return chunk ? RRTMGP_OK : st.finish();
 }
@@ -622,7 +639,14 @@ static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSli
     o.col_offset += (int64_t)s.c0;
 }
 
-static void slice_lw_bcs(rrtmgp_lw_bcs &b, const ColumnSlice &s, size_t nbnd) { b.sfc_emis = s.adv(b.sfc_emis, nbnd); }
+// `ncol` = columns of the array being sliced (the leading dimension of its inc_flux unless the caller gave one)
+static void slice_lw_bcs(rrtmgp_lw_bcs &b, const ColumnSlice &s, size_t nbnd, size_t ncol) {
+    b.sfc_emis = s.adv(b.sfc_emis, nbnd);
+    if (b.inc_flux) {
+        if (b.inc_flux_ld <= 0) b.inc_flux_ld = (int32_t)ncol;
+        b.inc_flux = s.adv(b.inc_flux, 1);
+    }
+}
 static void slice_sw_bcs(rrtmgp_sw_bcs &b, const ColumnSlice &s, size_t nbnd) {
     b.cos_zenith = s.adv(b.cos_zenith, 1); b.toa_flux = s.adv(b.toa_flux, 1);
     b.sfc_alb_direct = s.adv(b.sfc_alb_direct, nbnd); b.sfc_alb_diffuse = s.adv(b.sfc_alb_diffuse, nbnd);
@@ -648,7 +672,6 @@ static int check_multi(const rrtmgp_workspace *ws, int state_mem, int bcs_mem, c
         return set_error(RRTMGP_EUNSUPPORTED, "multi-shard solves need the (nlev, ncol) flux layout: ncol must be the slowest dimension");
     if (flux && (flux->band_flux_up || flux->band_flux_dn || flux->band_flux_net))
         return set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes cannot be sharded in one call");
-    if (inc_flux) return set_error(RRTMGP_EUNSUPPORTED, "LwBCs.inc_flux (ncol fastest) cannot be sharded in one call");
     return RRTMGP_OK;
 }
 
@@ -749,12 +772,12 @@ static int solve_lw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     TRY(pin_lw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts));
-    if (!bcs || bcs->inc_flux || !host_pipeline_applies(as, bcs->mem, flux, opts))
+    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts))
         return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
     return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
                              [&](rrtmgp_atmos_state &a, rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &sl, Stager &st) {
                                  rrtmgp_lw_bcs b = *bcs;
-                                 b.sfc_emis = sl.adv(b.sfc_emis, (size_t)lk.n_bnd);
+                                 slice_lw_bcs(b, sl, (size_t)lk.n_bnd, (size_t)as->ncol);
                                  return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, &a, &b, &f, &o, &st);
                              });
 }
@@ -1125,7 +1148,7 @@ int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *l
         TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
         return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
-                              [nb](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb); },
+                              [nb, as](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb, (size_t)as->ncol); },
                               rrtmgp_hip_rte_lw_2stream_solve);
     }
     TRY(check_common(ws, lookup_lw, 0, cld, aero, as));
@@ -1143,7 +1166,7 @@ int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
         TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
         return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
-                              [nb](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb); },
+                              [nb, as](rrtmgp_lw_bcs &b, const ColumnSlice &sl) { slice_lw_bcs(b, sl, nb, (size_t)as->ncol); },
                               rrtmgp_hip_rte_lw_noscat_solve);
     }
     TRY(check_common(ws, lookup_lw, 0, cld, aero, as));

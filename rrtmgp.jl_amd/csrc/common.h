@@ -190,7 +190,7 @@ int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, 
 // Launchers implemented in the .hip translation units.  `which`: 1 = two-stream, 0 = no-scattering.
 template <typename FT>
 int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
-              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl, int n_angles,
+              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, int inc_ld, const DevFlux<FT> &fl, int n_angles,
               uint64_t seed, int64_t col_offset, int max_minor);
 template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,

@@ -75,7 +75,8 @@ struct LwArgs {
     DevState<FT> as;
     DevFlux<FT> fl;
     const FT *sfc_emis;  // (nbnd, ncol)
-    const FT *inc_flux;  // (ncol, ngpt) or nullptr
+    const FT *inc_flux;  // (inc_ld, ngpt) or nullptr: column col of g-point g at col + inc_ld * g
+    int inc_ld;
     FT *scratch;
     int *queue;  // next column of the persistent grid (device counter, zeroed before the launch)
     ColDims dims;
@@ -156,7 +157,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             if (lane == 0) sh.misc[wave] = __popcll(b);
         }
         const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
-        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)ncol * g] : FT(0);
+        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)a.inc_ld * g] : FT(0);
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
@@ -420,13 +421,13 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, c
 
 template <typename FT>
 int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
-              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, const DevFlux<FT> &fl, int n_angles,
+              const DevState<FT> &as, const FT *sfc_emis, const FT *inc_flux, int inc_ld, const DevFlux<FT> &fl, int n_angles,
               uint64_t seed, int64_t col_offset, int max_int) {
     LwArgs<FT> a{};
     a.lk = lk;
     if (cld) a.cld = *cld;
     if (aero) a.aero = *aero;
-    a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux;
+    a.as = as; a.fl = fl; a.sfc_emis = sfc_emis; a.inc_flux = inc_flux; a.inc_ld = inc_ld;
     a.seed = seed; a.col_offset = col_offset;
     const int threads = ((fl.band_up ? lk.band_rows * 16 : lk.n_gpt) + 63) / 64 * 64;
     RR_CHECK(threads <= 256, "n_gpt > 256 is not supported");
@@ -481,10 +482,10 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
 }
 
 template int launch_lw<float>(rrtmgp_workspace *, int, const DevGas<float> &, const DevCld<float> *,
-                              const DevAero<float> *, const DevState<float> &, const float *, const float *,
+                              const DevAero<float> *, const DevState<float> &, const float *, const float *, int,
                               const DevFlux<float> &, int, uint64_t, int64_t, int);
 template int launch_lw<double>(rrtmgp_workspace *, int, const DevGas<double> &, const DevCld<double> *,
-                               const DevAero<double> *, const DevState<double> &, const double *, const double *,
+                               const DevAero<double> *, const DevState<double> &, const double *, const double *, int,
                                const DevFlux<double> &, int, uint64_t, int64_t, int);
 
 }  // namespace rrtmgp

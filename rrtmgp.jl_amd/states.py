@@ -176,11 +176,28 @@ class AtmosphericState(_Container):
 class LwBCs(_Container):
     sfc_emis: object          # (nbnd, ncol)
     inc_flux: object = None   # (ncol, ngpt) or None
+    inc_flux_ld: int = 0      # > 0: `inc_flux` is a block of columns of a wider (inc_flux_ld, ngpt) array (a view)
 
     def desc(self) -> _abi.LwBcs:
         d = _abi.LwBcs()
         mems = set()
-        self._set_ptrs(d, ("sfc_emis", "inc_flux"), mems)
+        if self.inc_flux_ld and self.inc_flux is not None:
+            self._set_ptrs(d, ("sfc_emis",), mems)
+            x, ld = self.inc_flux, int(self.inc_flux_ld)
+            if isinstance(x, np.ndarray):   # (ncol, ngpt) view: unit stride along columns, ld elements between g-points
+                if x.strides != (x.itemsize, ld * x.itemsize):
+                    raise ValueError("inc_flux must be a column block of a column-major (inc_flux_ld, ngpt) array")
+                d.inc_flux, m = x.ctypes.data, _abi.MEM_HOST
+            else:                           # torch sees the reversed shape: (ngpt, ncol) with strides (ld, 1)
+                if tuple(x.stride()) != (ld, 1):
+                    raise ValueError("inc_flux must be a column block of a (ngpt, inc_flux_ld) tensor")
+                d.inc_flux, m = x.data_ptr(), (_abi.MEM_DEVICE if x.is_cuda else _abi.MEM_HOST)
+            mems.add(m)
+            d.inc_flux_ld = ld
+        else:
+            self._set_ptrs(d, ("sfc_emis", "inc_flux"), mems)
+        if len(mems) != 1:
+            raise ValueError("sfc_emis and inc_flux must live in the same memory space")
         d.mem = mems.pop()
         return d
 

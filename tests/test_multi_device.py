@@ -99,14 +99,58 @@ def test_noscat_gray_and_preparation_steps_on_shards(tables64):
         np.testing.assert_array_equal(many.as_nlev_ncol(n), a[n])
 
 
+@pytest.mark.parametrize("twostream", [True, False])
+def test_incident_flux_is_sharded_as_a_2d_block(tables64, twostream):
+    """LwBCs.inc_flux is (ncol, ngpt): ncol is its FASTEST dimension, so a shard's column range is `ngpt` rows of a
+    wider array.  The library hands such blocks around with a leading dimension (`inc_flux_ld`) and packs them while
+    staging; same bits as the single launch."""
+    t = tables64
+    as_, lb, sb = S.make_columns(11, 16, np.float64, seed=2, inc_flux_ngpt=t["lw"].n_gpt)
+    nlay, ncol = as_.dims
+    cls = rte.TwoStreamLWRTE if twostream else rte.NoScatLWRTE
+    one = rte.solve_lw(cls(ncol, nlay, np.float64, lb), as_, t["lw"], t["cld_lw"], seed=3)
+    ws = rte.Workspace(ncol, nlay, np.float64, [0, 0, 0])
+    dl, dc = rte.DeviceLookup(t["lw"], [0, 0, 0]), rte.DeviceLookup(t["cld_lw"], [0, 0, 0])
+    many = rte.solve_lw(cls(ncol, nlay, np.float64, lb, workspace=ws), as_, dl, dc, seed=3)
+    for n in LWN:
+        np.testing.assert_array_equal(many.as_nlev_ncol(n), one.as_nlev_ncol(n))
+    ref = O.solve_lw(as_, lb, t["lw"], t["cld_lw"], twostream=twostream, seed=3)
+    assert np.abs(many.as_nlev_ncol("flux_dn") - ref.flux_dn).max() < 1e-8
+    assert np.abs(many.as_nlev_ncol("flux_dn")[-1] - lb.inc_flux.sum(axis=1)).max() < 1e-9   # TOA dn == incident flux
+
+
+def test_incident_flux_block_of_a_wider_array_host_and_device(tables64):
+    """`inc_flux_ld` is public: a caller may pass columns [c0, c0 + ncol) of a wider (ncol_total, ngpt) array."""
+    import torch
+    t = tables64
+    as_, lb, sb = S.make_columns(9, 16, np.float64, seed=4, inc_flux_ngpt=t["lw"].n_gpt)
+    nlay, ncol = as_.dims
+    ref = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb), as_, t["lw"])
+    wide = np.asfortranarray(np.full((ncol + 7, t["lw"].n_gpt), np.nan))
+    wide[3:3 + ncol] = lb.inc_flux
+    # host block
+    blk = LwBCs(sfc_emis=lb.sfc_emis, inc_flux=wide[3:3 + ncol], inc_flux_ld=ncol + 7)
+    out = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, blk), as_, t["lw"])
+    for n in LWN:
+        np.testing.assert_array_equal(out.as_nlev_ncol(n), ref.as_nlev_ncol(n))
+    # device block: read in place with the stride
+    wd = torch.as_tensor(np.ascontiguousarray(wide.T), device="cuda:0")   # torch (ngpt, ncol_total) == Fortran (ncol_total, ngpt)
+    dblk = LwBCs(sfc_emis=torch.as_tensor(np.ascontiguousarray(lb.sfc_emis.T), device="cuda:0"),
+                 inc_flux=wd[:, 3:3 + ncol], inc_flux_ld=ncol + 7)
+    slv = rte.TwoStreamLWRTE(ncol, nlay, np.float64, dblk, flux_device="cuda:0")
+    rte.solve_lw(slv, as_.to_device("cuda:0"), t["lw"])
+    slv.ws.synchronize()
+    got = slv.flux.to_host()
+    for n in LWN:
+        np.testing.assert_array_equal(got.as_nlev_ncol(n), ref.as_nlev_ncol(n))
+
+
 def test_what_cannot_be_sharded_is_rejected_loudly(tables64):
     t = tables64
     as_, lb, sb = S.make_columns(8, 16, np.float64, seed=2, inc_flux_ngpt=t["lw"].n_gpt)
     nlay, ncol = as_.dims
     ws = rte.Workspace(ncol, nlay, np.float64, [0, 0])
     dl = rte.DeviceLookup(t["lw"], [0, 0])
-    with pytest.raises(_lib.RRTMGPHipError, match="inc_flux"):
-        rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb, workspace=ws), as_, dl)
     lb2 = LwBCs(sfc_emis=lb.sfc_emis, inc_flux=None)
     with pytest.raises(_lib.RRTMGPHipError, match="layout"):
         rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb2, workspace=ws, layout=_abi.LAYOUT_NCOL_NLEV), as_, dl)
