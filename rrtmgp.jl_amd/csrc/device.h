@@ -317,6 +317,7 @@ struct ColShared {
     FT *acc;             // [nseg][nlev][n_acc]
     int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
     FT *miscf;           // [0]: pl_sfc_f
+    uint64_t *mask;      // McICA masks of columns with more than 128 layers and clouds: [word][256 lanes], else unused
     // TabCache: the small lookup tables the preparation steps index with data-dependent positions, copied once per
     // workgroup (not per column) so that those dependent reads are LDS round trips instead of L2 ones
     FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_vmr_ref;
@@ -348,6 +349,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
+    s.mask = carve<uint64_t>(p, d.has_cld && d.nlay > 128 ? (size_t)((d.nlay + 63) / 64 + 1) * 256 : 0);
     s.tab_t_ref = carve<FT>(p, d.n_t_ref);
     s.tab_ln_p_ref = carve<FT>(p, d.n_p_ref);
     s.tab_t_planck = carve<FT>(p, d.lw ? d.n_t_plnk : 0);
@@ -1001,13 +1003,41 @@ __device__ __forceinline__ void gas_optics(const DevGas<FT> &lk, const ColShared
 }
 
 // ---- McICA mask for this lane's g-point: cloud_optics.jl:264-334 ----------------------------
-// Bits of (m0, m1) are layers 0..63 / 64..127.  Returns any(mask).
+// Bits of (m0, m1) are layers 0..63 / 64..127.  Columns with more than 128 layers keep one 64-bit word per 64 layers
+// in LDS instead (sh.mask[word * 256 + lane]: only this lane reads them back, no barrier).  Returns any(mask).
 template <typename FT, int CHK>
 __device__ inline bool build_cloud_mask(const ColShared<FT, CHK> &sh, const ColDims &d, uint64_t key, uint64_t &m0,
                                         uint64_t &m1) {
     m0 = m1 = 0;
     const int start = sh.misc[d.nwaves + 1], finish = sh.misc[d.nwaves + 2];
+    const bool big = d.nlay > 128;
+    if (big)
+        for (int w = 0; w < (d.nlay + 63) / 64; w++) sh.mask[w * 256 + threadIdx.x] = 0;
     if (start < 0) return false;
+    if (big) {
+        int draw = 0, widx = finish >> 6;
+        uint64_t wcur = 0;
+        bool any = false;
+        FT cf_above = sh.lay[finish].cld_frac;
+        double r_above = mcica_draw(key, draw++);
+        bool mask_above = r_above >= (double)(FT(1) - cf_above);
+        if (mask_above) { wcur |= 1ULL << (finish & 63); any = true; }
+        for (int k = finish - 1; k >= start; k--) {
+            if ((k >> 6) != widx) { sh.mask[widx * 256 + threadIdx.x] = wcur; wcur = 0; widx = k >> 6; }
+            const FT cf = sh.lay[k].cld_frac;
+            bool mk = false;
+            if (cf > FT(0)) {
+                const double r = mask_above ? r_above : mcica_draw(key, draw++) * (double)(FT(1) - cf_above);
+                mk = r >= (double)(FT(1) - cf);
+                r_above = r;
+            }
+            if (mk) { wcur |= 1ULL << (k & 63); any = true; }
+            cf_above = cf;
+            mask_above = mk;
+        }
+        sh.mask[widx * 256 + threadIdx.x] = wcur;
+        return any;
+    }
     int draw = 0;
     FT cf_above = sh.lay[finish].cld_frac;
     double r_above = mcica_draw(key, draw++);
@@ -1039,14 +1069,31 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
 template <bool UP>
 struct MaskWalk {
     uint64_t cur, other;
-    int k;  // layer `cur` is positioned at (wave-uniform)
-    __device__ __forceinline__ MaskWalk(uint64_t m0, uint64_t m1, int nlay) {
-        if (UP) { cur = m0; other = m1; k = 0; }
+    const uint64_t *base;  // wave-uniform; != nullptr: more than 128 layers, lane t's word w is base[w * 256 + t] (LDS)
+    __device__ __forceinline__ const uint64_t *word(int w) const { return base + w * 256 + threadIdx.x; }
+    __device__ __forceinline__ MaskWalk(uint64_t m0, uint64_t m1, int nlay, const uint64_t *lds_words = nullptr) {
+#ifdef RR_EXP_MASK_128_ONLY  // A/B: the register-only walker of columns up to 128 layers
+        base = nullptr;
+#else
+        base = nlay > 128 ? lds_words : nullptr;
+#endif
+        if (base) {
+            const int top = (nlay - 1) >> 6;
+            cur = UP ? *word(0) : *word(top) << (63 - ((nlay - 1) & 63));
+            other = UP ? *word(1) : *word(top - 1);
+        } else if (UP) { cur = m0; other = m1; }
         else {
-            k = nlay - 1;
             if (nlay > 64) { cur = m1 << (128 - nlay); other = m0; }
             else { cur = m0 << (64 - nlay); other = 0; }
         }
+    }
+    // Deep columns: `other` = the word after the current one, fetched from LDS once per 64 layers.  Called at the start
+    // of every chunk with the first layer of the chunk in walking order (chunk edges fall on word edges), so the
+    // per-layer step below never touches memory.
+    __device__ __forceinline__ void refill(int k_edge) {
+        if (!base) return;
+        if (UP) { if ((k_edge & 63) == 0) other = *word((k_edge >> 6) + 1); }   // (one word past the last is allocated)
+        else if ((k_edge & 63) == 63 && k_edge >= 64) other = *word((k_edge >> 6) - 1);
     }
     // the bit of layer `kq`, which must be the next one in walking order
     __device__ __forceinline__ bool next(int kq) {
@@ -1054,11 +1101,11 @@ struct MaskWalk {
         if (UP) {
             b = (unsigned)cur & 1u;
             cur >>= 1;
-            if (kq == 63) cur = other;
+            if ((kq & 63) == 63) cur = other;
         } else {
             b = (long long)cur < 0;
             cur <<= 1;
-            if (kq == 64) cur = other;
+            if ((kq & 63) == 0) cur = other;
         }
         return b;
     }

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
-        MaskWalk<true> mw(m0, m1, nlay);  // both LW solvers visit the layers bottom-up
+        MaskWalk<true> mw(m0, m1, nlay, sh.mask);  // both LW solvers visit the layers bottom-up
 
         if (TWOSTREAM) {
             // ---- bottom-up: optics + sources, and one layer behind them coefficients + adding
@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             };
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
+                mw.refill(k0);
                 RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE  // timing-only experiment: chunk records prepared for the first chunk only (barriers kept)
                 if (c == 0)
@@ -330,6 +331,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             FT inc_prev = FT(0);
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
+                mw.refill(k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
                 RR_CHUNK_SYNC();
@@ -445,7 +447,6 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nslot0 = lk.m_nslot[0]; d.nslot1 = lk.m_nslot[1]; d.nbnd = lk.n_bnd; d.lw = 1; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 4 : 2; d.diag = diag; d.max_int = max_int;
-    RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     a.n_angles = twostream ? 1 : n_angles;
     double Ds[4], wts[4];

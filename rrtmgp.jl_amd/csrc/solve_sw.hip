@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             // one stream of the top-down adding: all-sky, and (DIAG) its clear-sky twin
             struct Stream { FT tau_cum, dir_above, beta, delta; };
             Stream S{FT(0), dir_top, FT(0), FT(0)}, C{FT(0), dir_top, FT(0), FT(0)};
-            MaskWalk<false> mw(m0, m1, nlay);  // top-down
+            MaskWalk<false> mw(m0, m1, nlay, sh.mask);  // top-down
             {
                 const FT s = seg_sum<BAND>(dir_top * amask);
                 if (writer) {
@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             };
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
+                mw.refill(k0 + kn - 1);
                 RR_CHUNK_SYNC();
 #ifdef RR_EXP_PREP_ONCE
                 if (c == nchunk - 1)
@@ -379,7 +380,6 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     d.nint0 = lk.m_nint[0]; d.nint1 = lk.m_nint[1]; d.nslot0 = lk.m_nslot[0]; d.nslot1 = lk.m_nslot[1]; d.nbnd = lk.n_bnd; d.lw = 0; d.twostream = twostream;
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 6 : 3; d.diag = diag; d.max_int = max_int;
-    RR_CHECK(!d.has_cld || d.nlay <= 128, "cloudy solves support at most 128 layers");
     a.dims = d;
     // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
     const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));

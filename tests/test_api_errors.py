@@ -34,11 +34,10 @@ def test_dimension_and_lookup_mismatches(tables64, small_tables64):
     # n_gauss_angles outside 1..4 (AngularDiscretizations.jl:34-63)
     with pytest.raises(_lib.RRTMGPHipError, match="n_gauss_angles"):
         rte.solve_lw(rte.NoScatLWRTE(5, 16, np.float64, lb, n_gauss_angles=5), as_, t["lw"])
-    # cloudy solves are limited to 128 layers (two 64-bit McICA mask words per g-point)
-    big, lbb, _ = S.make_columns(2, 130, seed=1)
-    with pytest.raises(_lib.RRTMGPHipError, match="128 layers"):
-        rte.solve_lw(rte.TwoStreamLWRTE(2, 130, np.float64, lbb), big, t["lw"], t["cld_lw"])
-    rte.solve_lw(rte.TwoStreamLWRTE(2, 130, np.float64, lbb), big, t["lw"])   # clear sky is fine
+    # the one size limit left: a column's records must fit the 160 KB LDS of a CU (Float64: ~250 layers)
+    big, lbb, _ = S.make_columns(2, 400, seed=1)
+    with pytest.raises(_lib.RRTMGPHipError, match="160 KB LDS"):
+        rte.solve_lw(rte.TwoStreamLWRTE(2, 400, np.float64, lbb), big, t["lw"], t["cld_lw"])
     # the error text is available through the C entry point as well
     buf = C.create_string_buffer(256)
     assert _lib.lib().rrtmgp_hip_last_error(buf, 256) == 0

@@ -135,6 +135,26 @@ def test_partial_cloud_fraction_masks_match(tables64):
         np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, cref)
 
 
+@pytest.mark.parametrize("nlay", [129, 150, 200])
+def test_deep_columns_with_clouds(tables64, nlay):
+    """More than 128 layers with clouds: the McICA mask no longer fits two 64-bit registers per g-point; its words live
+    in LDS and the walkers fetch one per 64 layers.  Masks, cover and fluxes as the oracle's, both sweep directions."""
+    t = tables64
+    as_, lb, sb = S.make_columns(5, nlay, np.float64, seed=nlay, random_cld_frac=True, night_fraction=0.2)
+    for ts in (True, False):
+        ref = O.solve_lw(as_, lb, t["lw"], t["cld_lw"], twostream=ts, seed=4)
+        cref = as_.cloud_state.cld_cover_lw.copy()
+        out = hip_lw(as_, lb, t["lw"], t["cld_lw"], twostream=ts, seed=4)
+        assert maxdiff(out, ref, LWN) < 1e-8
+        np.testing.assert_array_equal(as_.cloud_state.cld_cover_lw, cref)
+    ref = O.solve_sw(as_, sb, t["sw"], t["cld_sw"], seed=4)
+    cref = as_.cloud_state.cld_cover_sw.copy()
+    out = hip_sw(as_, sb, t["sw"], t["cld_sw"], seed=4)
+    assert maxdiff(out, ref, SWN) < 1e-8
+    np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, cref)
+    assert cref.max() > 0 and np.all((cref >= 0) & (cref <= 1))
+
+
 def test_reduced_tables_ragged_bands_and_odd_sizes(small_tables64):
     """Bands of 8/4/12 (LW) and 6/10/4 (SW) g-points, nlay = 3 and 73, ncol = 1 and 5."""
     t = small_tables64
