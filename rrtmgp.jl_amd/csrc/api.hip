@@ -93,6 +93,20 @@ int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes) {
     return RRTMGP_OK;
 }
 
+static int bounce_ensure(rrtmgp_workspace *ws, size_t bytes) {
+    if (ws->bounce_bytes >= bytes) return RRTMGP_OK;
+    RR_HIP(hipStreamSynchronize(ws->stream));
+    if (ws->bounce_h) RR_HIP(hipHostFree(ws->bounce_h));
+    if (ws->bounce_d) RR_HIP(rr_free(ws->bounce_d));
+    ws->bounce_h = ws->bounce_d = nullptr;
+    ws->bounce_bytes = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    RR_HIP(hipHostMalloc((void **)&ws->bounce_h, cap, hipHostMallocDefault));
+    RR_HIP(rr_malloc((void **)&ws->bounce_d, cap));
+    ws->bounce_bytes = cap;
+    return RRTMGP_OK;
+}
+
 int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
     if (ws->scratch.bytes >= bytes && ws->scratch.ptr) return RRTMGP_OK;
     if (ws->scratch.ptr) {
@@ -369,12 +383,31 @@ struct Stager {
     bool pin_only = false;     // registration pass over the caller's WHOLE host arrays: no copies, no device memory
     uint64_t keep = 0;         // pipelined host path, bit per slot: the array does not depend on the column range and an
                                // earlier chunk has already put it into this staging set
+    // small solves (packed): host arrays are copied into / out of the workspace's page-locked bounce buffer by the CPU
+    // and cross PCIe in ONE transfer each way; `need` = what the registration pass found the solve to stage
+    bool packed = false;
+    size_t need = 0, off = 0, in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
+    static size_t al(size_t n) { return (n + 255) & ~size_t(255); }
     hipStream_t copy_stream() const { return cs ? cs : ws->stream; }
     bool pin(int mem, const void *p, size_t bytes, void **out) {
         if (!pin_only) return false;
-        if (mem == RRTMGP_MEM_HOST) host_pin(ws, p, bytes);
+        if (mem == RRTMGP_MEM_HOST) { host_pin(ws, p, bytes); need += al(bytes); }
         *out = nullptr;
         return true;
+    }
+    // reserves `bytes` of the bounce buffer (sized from the registration pass over the same arguments)
+    int take(size_t bytes, bool input, bool output, size_t *o) {
+        if (off + al(bytes) > ws->bounce_bytes) return set_error(RRTMGP_EINVAL, "internal: bounce buffer smaller than the staged arrays");
+        *o = off;
+        off += al(bytes);
+        if (input) in_hi = off;
+        if (output) { out_lo = std::min(out_lo, *o); out_hi = off; }
+        return RRTMGP_OK;
+    }
+    // packed mode: the one upload, on the compute stream, right before the launch
+    int flush() {
+        if (packed && in_hi) RR_HIP(hipMemcpyAsync(ws->bounce_d, ws->bounce_h, in_hi, hipMemcpyHostToDevice, ws->stream));
+        return RRTMGP_OK;
     }
 
     // input: returns device pointer (copying H2D if mem == host)
@@ -382,6 +415,13 @@ struct Stager {
         if (!p) { *out = nullptr; return RRTMGP_OK; }
         if (pin(mem, p, bytes, const_cast<void **>(out))) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *out = p; return RRTMGP_OK; }
+        if (packed) {
+            size_t o;
+            TRY(take(bytes, true, false, &o));
+            memcpy(ws->bounce_h + o, p, bytes);
+            *out = ws->bounce_d + o;
+            return RRTMGP_OK;
+        }
         TRY(stage_ensure(ws, slot, bytes));
         if (!((keep >> slot) & 1)) RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
@@ -389,7 +429,14 @@ struct Stager {
     }
     // input, HOST memory only: `height` rows of `width` bytes, `spitch` bytes apart at the source, packed in the staging buffer
     int in2d(int slot, const void *p, size_t width, size_t height, size_t spitch, const void **out) {
-        if (pin_only) { *out = nullptr; return RRTMGP_OK; }  // the registration pass sees whole arrays (in())
+        if (pin_only) { need += al(width * height); *out = nullptr; return RRTMGP_OK; }  // (registration: whole arrays, in())
+        if (packed) {
+            size_t o;
+            TRY(take(width * height, true, false, &o));
+            for (size_t r = 0; r < height; r++) memcpy(ws->bounce_h + o + r * width, (const char *)p + r * spitch, width);
+            *out = ws->bounce_d + o;
+            return RRTMGP_OK;
+        }
         TRY(stage_ensure(ws, slot, width * height));
         RR_HIP(hipMemcpy2DAsync(ws->stage[slot].ptr, width, p, spitch, width, height, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
@@ -400,6 +447,13 @@ struct Stager {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
         if (pin(mem, p, bytes, outp)) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *outp = p; return RRTMGP_OK; }
+        if (packed) {
+            size_t o;
+            TRY(take(bytes, false, true, &o));
+            *outp = ws->bounce_d + o;
+            backs.push_back({p, ws->bounce_d + o, bytes});
+            return RRTMGP_OK;
+        }
         TRY(stage_ensure(ws, slot, bytes));
         *outp = ws->stage[slot].ptr;
         backs.push_back({p, ws->stage[slot].ptr, bytes});
@@ -410,6 +464,14 @@ struct Stager {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
         if (pin(mem, p, bytes, outp)) return RRTMGP_OK;
         if (mem == RRTMGP_MEM_DEVICE) { *outp = const_cast<void *>(p); return RRTMGP_OK; }
+        if (packed) {
+            size_t o;
+            TRY(take(bytes, true, true, &o));
+            memcpy(ws->bounce_h + o, p, bytes);
+            *outp = ws->bounce_d + o;
+            backs.push_back({const_cast<void *>(p), ws->bounce_d + o, bytes});
+            return RRTMGP_OK;
+        }
         TRY(stage_ensure(ws, slot, bytes));
         RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *outp = ws->stage[slot].ptr;
@@ -417,6 +479,13 @@ struct Stager {
         return RRTMGP_OK;
     }
     int finish() {
+        if (packed) {
+            if (out_hi > out_lo)
+                RR_HIP(hipMemcpyAsync(ws->bounce_h + out_lo, ws->bounce_d + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, ws->stream));
+            RR_HIP(hipStreamSynchronize(ws->stream));
+            for (auto &b : backs) memcpy(b.host, ws->bounce_h + ((char *)b.dev - ws->bounce_d), b.bytes);
+            return RRTMGP_OK;
+        }
         if (backs.empty()) return RRTMGP_OK;
         for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ws->stream));
         RR_HIP(hipStreamSynchronize(ws->stream));
@@ -561,13 +630,14 @@ static int solve_lw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, as->ncol, as->nlay + 1, false, fl, twostream ? (size_t)lk.n_bnd : 0));
     if (st.pin_only) return RRTMGP_OK;
-    if (chunk) {  // pipelined host path: the uploads ran on the copy stream
+    if (chunk && !st.packed) {  // pipelined host path: the uploads ran on the copy stream
         RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
     }
+    TRY(st.flush());  // packed small solve: the one upload
     TRY(launch_lw<FT>(ws, twostream, lk, cld, aero, ds, emis, inc, inc_ld, fl, n_angles, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
-    return chunk ? RRTMGP_OK : st.finish();
+    return chunk && !st.packed ? RRTMGP_OK : st.finish();
 }
 
 template <typename FT>
@@ -592,13 +662,14 @@ static int solve_sw_t(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk,
     DevFlux<FT> fl;
     TRY(stage_flux(st, flux, opts, ncol, as->nlay + 1, true, fl, twostream ? (size_t)lk.n_bnd : 0));
     if (st.pin_only) return RRTMGP_OK;
-    if (chunk) {
+    if (chunk && !st.packed) {  // pipelined host path: the uploads ran on the copy stream
         RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
     }
+    TRY(st.flush());  // packed small solve: the one upload
     TRY(launch_sw<FT>(ws, twostream, lk, cld, aero, ds, mu0, toa, adir, adif, fl, opts ? opts->seed : 0,
                       opts ? opts->col_offset : 0, max_minor));
-    return chunk ? RRTMGP_OK : st.finish();
+    return chunk && !st.packed ? RRTMGP_OK : st.finish();
 }
 
 // ---- pipelined host path ------------------------------------------------------------------
@@ -749,31 +820,50 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
     return rc;
 }
 
+// Below this many staged host bytes a solve goes through the bounce buffer (Stager::packed): per-array DMA commands
+// cost ~15 us each whatever their size, a host memcpy ~0.1 us per KB (RRTMGP_HIP_HOST_PACK_BYTES overrides, 0 = never).
+static size_t host_pack_max() {
+    static const size_t v = getenv("RRTMGP_HIP_HOST_PACK_BYTES") ? (size_t)atoll(getenv("RRTMGP_HIP_HOST_PACK_BYTES")) : (size_t)2 << 20;
+    return v;
+}
+
 // page-lock the caller's WHOLE host arrays (does something on the first call only); `ws` owns the registrations
 template <typename FT>
 static int pin_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
                   int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
-                  const rrtmgp_solve_opts *opts) {
+                  const rrtmgp_solve_opts *opts, size_t *need = nullptr) {
     Stager pin{ws, {}};
     pin.pin_only = true;
-    return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+    const int rc = solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+    if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
+    return rc;
 }
 template <typename FT>
 static int pin_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
                   int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux,
-                  const rrtmgp_solve_opts *opts) {
+                  const rrtmgp_solve_opts *opts, size_t *need = nullptr) {
     Stager pin{ws, {}};
     pin.pin_only = true;
-    return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+    const int rc = solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
+    if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
+    return rc;
 }
 
 template <typename FT>
 static int solve_lw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(pin_lw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts));
-    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts))
+    size_t need = 0;
+    TRY(pin_lw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &need));
+    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts)) {
+        if (need && need <= host_pack_max()) {   // small solve: one bounce buffer, one DMA each way
+            TRY(bounce_ensure(ws, need));
+            Stager st{ws, {}};
+            st.packed = true;
+            return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &st);
+        }
         return solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
+    }
     return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
                              [&](rrtmgp_atmos_state &a, rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &sl, Stager &st) {
                                  rrtmgp_lw_bcs b = *bcs;
@@ -786,9 +876,17 @@ template <typename FT>
 static int solve_sw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld,
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
-    TRY(pin_sw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts));
-    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts))
+    size_t need = 0;
+    TRY(pin_sw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &need));
+    if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts)) {
+        if (need && need <= host_pack_max()) {
+            TRY(bounce_ensure(ws, need));
+            Stager st{ws, {}};
+            st.packed = true;
+            return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &st);
+        }
         return solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts);
+    }
     return run_host_pipeline(ws, as, flux, opts, sizeof(FT),
                              [&](rrtmgp_atmos_state &a, rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &sl, Stager &st) {
                                  rrtmgp_sw_bcs b = *bcs;
@@ -1048,6 +1146,8 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
     }
     if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
     if (ws->scratch.ptr) (void)rr_free(ws->scratch.ptr);
+    if (ws->bounce_h) (void)hipHostFree(ws->bounce_h);
+    if (ws->bounce_d) (void)rr_free(ws->bounce_d);
     if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);
     if (ws->ev_stop) (void)hipEventDestroy(ws->ev_stop);
     if (ws->own_stream) (void)hipStreamDestroy(ws->own_stream);

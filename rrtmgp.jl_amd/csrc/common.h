@@ -142,6 +142,10 @@ struct rrtmgp_workspace {
     std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
+    // small host-array solves: every array travels through ONE page-locked bounce buffer (a host memcpy per array, one
+    // DMA each way) instead of one DMA per array (~15 us each, 17 arrays per solve)
+    char *bounce_h = nullptr, *bounce_d = nullptr;
+    size_t bounce_bytes = 0;
     // per-(block, level, lane) scratch of the vertical sweeps
     rrtmgp::DeviceBuffer scratch;
     // resident workgroups per CU of each (kernel, dynamic LDS size) launched so far
