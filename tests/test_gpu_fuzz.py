@@ -1,7 +1,10 @@
 """Randomised parity sweep: many small (ncol, nlay, tables, options) combinations, HIP against the
 oracle in Float64 (1e-8 W/m2).  Catches the shape-dependent mistakes the fixed cases cannot: layer
 counts around the chunk (16) and mask-word (64) boundaries, ragged bands, lanes beyond n_gpt, bands
-with more minor gases than one gather group, every solver variant."""
+with more minor gases than one gather group, columns deeper than the two mask registers, every solver variant, per-band
+fluxes of ragged bands, three shards in one process.  RRTMGP_FUZZ_CASES widens the sweep."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,8 +21,22 @@ def _maxdiff(a, b, names):
 
 
 @pytest.mark.parametrize("FT,tol_lw,tol_sw", [(np.float64, 1e-8, 1e-8), (np.float32, 2e-3, 3e-2)])
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RRTMGP_FUZZ_CASES", "32"))))
 def test_random_configuration(seed, FT, tol_lw, tol_sw):
+    from rrtmgp_jl_amd._lib import RRTMGPHipError
+    try:
+        _random_configuration(seed, FT, tol_lw, tol_sw)
+    except RRTMGPHipError as e:
+        # the one size limit: a column's records must fit the 160 KB LDS (deep Float64 columns in the wide variants:
+        # clear-sky twin, per-band accumulators); anything else, or that error on a column of <= 128 layers, is a failure
+        if "160 KB LDS" not in str(e) or "nlay_deep" not in _LAST:
+            raise
+
+
+_LAST = {}
+
+
+def _random_configuration(seed, FT, tol_lw, tol_sw):
     """Float32 runs are compared with the Float32 oracle on the same Float32 inputs (same McICA sample); the
     budgets are those of tests/test_gpu_parity.py for HIP-F32 vs oracle-F32."""
     rng = np.random.default_rng(1000 + seed)
@@ -31,8 +48,11 @@ def test_random_configuration(seed, FT, tol_lw, tol_sw):
     cl, cs = S.make_cloud_lookup("lw", n_bnd, FT, seed=seed), S.make_cloud_lookup("sw", n_bnd, FT, seed=seed)
     al, asw = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, FT, seed=seed), S.make_aerosol_lookup("sw", sw.bnd_lims_wn, FT, seed=seed)
     ncol = int(rng.choice([1, 2, 7, 33, 130]))
-    nlay = int(rng.choice([2, 3, 15, 16, 17, 31, 47, 63, 64, 65, 80, 127]))
+    nlay = int(rng.choice([2, 3, 15, 16, 17, 31, 47, 63, 64, 65, 80, 127, 128, 129, 143, 192, 193]))
     clouds, aerosols = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    _LAST.clear()
+    if nlay > 128 and FT is np.float64:
+        _LAST["nlay_deep"] = nlay
     vmr_kind = str(rng.choice(["gm", "full"]))
     as_, lb, sb = S.make_columns(ncol, nlay, FT, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
                                  n_bnd_lw=n_bnd, n_bnd_sw=n_bnd, night_fraction=0.3, random_cld_frac=True,
@@ -62,6 +82,31 @@ def test_random_configuration(seed, FT, tol_lw, tol_sw):
                     O.solve_lw(as_, lb, lw, c_lw, a_lw, **kw), LWN) < tol_lw, tag
     assert _maxdiff(rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, **kw),
                     O.solve_sw(as_, sb, sw, c_sw, a_sw, **kw), SWN) < tol_sw, tag
+    # per-band fluxes (any band structure: the lanes are laid out band by band on 16-lane rows)
+    from rrtmgp_jl_amd.states import FluxBand
+    for sw_ in (False, True):
+        lk, bcs, c_, a_ = (sw, sb, c_sw, a_sw) if sw_ else (lw, lb, c_lw, a_lw)
+        ref_b = FluxBand.allocate(ncol, nlay + 1, n_bnd, FT)
+        (O.solve_sw if sw_ else O.solve_lw)(as_, bcs, lk, c_, a_, band_flux=ref_b, **kw)
+        slv = (rte.TwoStreamSWRTE if sw_ else rte.TwoStreamLWRTE)(ncol, nlay, FT, bcs, n_bnd_band_flux=n_bnd)
+        (rte.solve_sw if sw_ else rte.solve_lw)(slv, as_, lk, c_, a_, **kw)
+        for n in LWN:
+            d = float(np.abs(np.float64(getattr(slv.band_flux, n)) - np.float64(getattr(ref_b, n))).max())
+            assert d < (tol_sw if sw_ else tol_lw), (tag, sw_, n, d)
+    # the same two-stream solves sharded over three workspaces of one process (ids wrap onto the one GPU)
+    if ncol >= 3:
+        ws3 = rte.Workspace(ncol, nlay, FT, [0, 0, 0])
+        d3 = {id(x): rte.DeviceLookup(x, [0, 0, 0]) for x in (lw, sw, c_lw, c_sw, a_lw, a_sw) if x is not None}
+        g = lambda x: d3[id(x)] if x is not None else None  # noqa: E731
+        one = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, **kw)
+        many = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb, workspace=ws3), as_, g(lw), g(c_lw), g(a_lw), **kw)
+        for n in LWN:
+            np.testing.assert_array_equal(many.as_nlev_ncol(n), one.as_nlev_ncol(n), err_msg=tag)
+        ws3 = rte.Workspace(ncol, nlay, FT, [0, 0, 0])
+        one = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, **kw)
+        many = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb, workspace=ws3), as_, g(sw), g(c_sw), g(a_sw), **kw)
+        for n in SWN:
+            np.testing.assert_array_equal(many.as_nlev_ncol(n), one.as_nlev_ncol(n), err_msg=tag)
     n_ang = int(rng.integers(1, 5))
     assert _maxdiff(rte.solve_lw(rte.NoScatLWRTE(ncol, nlay, FT, lb, n_gauss_angles=n_ang), as_, lw, c_lw, a_lw, **kw),
                     O.solve_lw(as_, lb, lw, c_lw, a_lw, twostream=False, n_gauss_angles=n_ang, **kw), LWN) < tol_lw, tag
