@@ -120,10 +120,12 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // AllSkyRadiationWithClearSkyDiagnostics (update_fluxes.jl:39-65), which the reference solves twice.
 // CA: -1 = clouds / aerosols are run-time flags; 0..3 = (clouds | aerosols << 1) known at compile time (the main
 // two-stream instance: absent optics leave no code, no kernel arguments in registers and no lane masks behind).
-template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
+// HALF: the main (no-aerosol) instances once more with 8-layer chunks, for columns whose 16-layer records would push a
+// workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = chunk_layers(CA, DIAG);  // layers per chunk of LDS records
+    constexpr int CHK = HALF ? CH / 2 : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -456,7 +458,13 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));
     ColShared<FT, chunk_layers(0)> dummy;
     ColShared<FT, chunk_layers(2)> dummy_aero;
-    const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
+    size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
+    // main Float32 instances: 8-layer chunks when that is what keeps 4 workgroups resident per CU (160 KB / 4).  Measured:
+    // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80
+    static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
+    const bool half = !no_half && sizeof(FT) == 4 && twostream && !diag && !fl.band_up && !aero && d.nlay <= 80 && lds > 40960 &&
+                      carve_shared(dummy_aero, (char *)nullptr, d) <= 40960;
+    if (half) lds = carve_shared(dummy_aero, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
@@ -465,6 +473,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : diag     ? (aero ? lw_solve_kernel<FT, true, false, true, 3> : lw_solve_kernel<FT, true, false, true, 1>)
                 : fl.band_up ? lw_solve_kernel<FT, true, true, false>
                 : (cld && aero) ? lw_solve_kernel<FT, true, false, false, 3>
+                : half ? (cld ? lw_solve_kernel<FT, true, false, false, 1, true> : lw_solve_kernel<FT, true, false, false, 0, true>)
                 : cld  ? lw_solve_kernel<FT, true, false, false, 1>
                 : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);

@@ -87,10 +87,12 @@ constexpr int DB = 16;  // levels per batch of the light sweeps
 
 // DIAG: clear-sky recurrences carried next to the all-sky ones (see lw_solve_kernel)
 // CA: see lw_solve_kernel
-template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1>
+// HALF: the main (no-aerosol) instances once more with 8-layer chunks, for columns whose 16-layer records would push a
+// workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
+template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = chunk_layers(CA, DIAG);  // layers per chunk of LDS records
+    constexpr int CHK = HALF ? CH / 2 : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -385,7 +387,13 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));
     ColShared<FT, chunk_layers(0)> dummy;
     ColShared<FT, chunk_layers(2)> dummy_aero;
-    const size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
+    size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
+    // main Float32 instances: 8-layer chunks when that is what keeps 4 workgroups resident per CU (160 KB / 4).  Measured:
+    // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80
+    static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
+    const bool half = !no_half && sizeof(FT) == 4 && twostream && !diag && !fl.band_up && !aero && d.nlay <= 80 && lds > 40960 &&
+                      carve_shared(dummy_aero, (char *)nullptr, d) <= 40960;
+    if (half) lds = carve_shared(dummy_aero, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
@@ -394,6 +402,7 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : diag     ? (aero ? sw_solve_kernel<FT, true, false, true, 3> : sw_solve_kernel<FT, true, false, true, 1>)
                 : fl.band_up ? sw_solve_kernel<FT, true, true, false>
                 : (cld && aero) ? sw_solve_kernel<FT, true, false, false, 3>
+                : half ? (cld ? sw_solve_kernel<FT, true, false, false, 1, true> : sw_solve_kernel<FT, true, false, false, 0, true>)
                 : cld  ? sw_solve_kernel<FT, true, false, false, 1>
                 : aero ? sw_solve_kernel<FT, true, false, false, 2> : sw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);

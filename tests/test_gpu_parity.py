@@ -155,6 +155,26 @@ def test_deep_columns_with_clouds(tables64, nlay):
     assert cref.max() > 0 and np.all((cref >= 0) & (cref <= 1))
 
 
+@pytest.mark.parametrize("nlay", [72, 80, 96])
+def test_float32_columns_of_71_to_80_layers_use_half_chunks(tables64, tables32, nlay):
+    """From 71 to 80 layers the Float32 main instances switch to 8-layer chunks of LDS records (4 resident workgroups
+    per CU instead of 3; beyond, 3 workgroups with 16-layer chunks are faster): same numbers either way, inside the
+    Float32 budget against the Float64 oracle."""
+    t, t64 = tables32, tables64
+    a64, lb64, sb64 = S.make_columns(12, nlay, np.float64, seed=nlay, random_cld_frac=True, night_fraction=0.2)
+    a32, lb32, sb32 = S.make_columns(12, nlay, np.float32, seed=nlay, random_cld_frac=True, night_fraction=0.2)
+    for cld in (True, False):
+        c_lw, c_sw = (t["cld_lw"], t["cld_sw"]) if cld else (None, None)
+        c64_lw, c64_sw = (t64["cld_lw"], t64["cld_sw"]) if cld else (None, None)
+        assert maxdiff(hip_lw(a32, lb32, t["lw"], c_lw, seed=2), O.solve_lw(a64, lb64, t64["lw"], c64_lw, seed=2), LWN) < 2e-3
+        assert maxdiff(hip_sw(a32, sb32, t["sw"], c_sw, seed=2), O.solve_sw(a64, sb64, t64["sw"], c64_sw, seed=2), SWN) < 1.2e-1
+        # and bit-equal to the Float32 oracle's McICA sample: cloud cover
+        if cld:
+            ref = S.make_columns(12, nlay, np.float32, seed=nlay, random_cld_frac=True, night_fraction=0.2)[0]
+            O.solve_lw(ref, lb32, t["lw"], c_lw, seed=2)
+            np.testing.assert_array_equal(a32.cloud_state.cld_cover_lw, ref.cloud_state.cld_cover_lw)
+
+
 def test_reduced_tables_ragged_bands_and_odd_sizes(small_tables64):
     """Bands of 8/4/12 (LW) and 6/10/4 (SW) g-points, nlay = 3 and 73, ncol = 1 and 5."""
     t = small_tables64
