@@ -439,8 +439,8 @@ int rrtmgp_hip_workspace_shards(const rrtmgp_workspace *ws);
 
 /* ---- allocation accounting (zero-allocation contract, update_fluxes.jl:215-218) ------------ */
 
-/* Device allocations (hipMalloc) and host registrations (hipHostRegister) the library has made
- * since it was loaded, all workspaces and lookups together.  A warm solve must not change them:
+/* Device allocations (hipMalloc) and page-locked host memory events (hipHostRegister of caller arrays,
+ * hipHostMalloc of the small-solve bounce buffer) the library has made since it was loaded, all workspaces and lookups together.  A warm solve must not change them:
  * tests/test_abi_contracts.py. */
 int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, int64_t *host_registrations);
 

@@ -102,6 +102,7 @@ static int bounce_ensure(rrtmgp_workspace *ws, size_t bytes) {
     ws->bounce_bytes = 0;
     const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 16);
     RR_HIP(hipHostMalloc((void **)&ws->bounce_h, cap, hipHostMallocDefault));
+    g_host_regs++;  // page-locked host memory: counted with the registrations (rrtmgp_hip_allocation_counts)
     RR_HIP(rr_malloc((void **)&ws->bounce_d, cap));
     ws->bounce_bytes = cap;
     return RRTMGP_OK;
