@@ -140,7 +140,8 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, c
         if (getenv("RRTMGP_HIP_TRACE_LAUNCH"))  // tuning aid: what decides the resident workgroups of this kernel variant
             fprintf(stderr, "rrtmgp_hip: kernel %p: %d threads, %zu B LDS -> %d workgroups per CU\n", kernel, threads, lds_bytes, n);
     }
-    const int per_cu = it->second;
+    static const int cap_per_cu = getenv("RRTMGP_HIP_MAX_WG_PER_CU") ? atoi(getenv("RRTMGP_HIP_MAX_WG_PER_CU")) : 0;  // tuning aid
+    const int per_cu = cap_per_cu > 0 ? std::min(it->second, cap_per_cu) : it->second;
     const int cap = ws->n_cu * per_cu;
     return std::max(1, std::min(ncol, cap));
 }
