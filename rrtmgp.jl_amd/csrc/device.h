@@ -175,6 +175,19 @@ __device__ __forceinline__ FT row_sum(FT v) {
     v += dpp_mov<0x140, 0xF>(v);
     return v;
 }
+// g-point sum of the layer loop into a per-wave LDS accumulator that was zeroed at the start of the column: the four
+// in-row DPP steps, then lanes 15 / 31 / 47 / 63 add their row's sum with ONE ds_add (the LDS serialises the four lanes
+// in a fixed order: reproducible).  Saves the two cross-row DPP steps (v_mov_dpp + v_add + hazard nops each) of
+// wave_sum_to_lane63: ~8 issue slots per sum in a loop that is VALU-issue bound.
+template <typename FT>
+__device__ __forceinline__ void wave_add_to(FT *slot, FT v) {
+    const FT rs = row_sum(v);
+    if ((threadIdx.x & 15) == 15) (void)__hip_atomic_fetch_add(slot, rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#ifndef RR_ACC_ATOMIC
+#define RR_ACC_ATOMIC 1
+#endif
+
 // The flux accumulators are kept per "segment": a whole wave (written by lane 63), or a
 // 16-lane row (written by its lane 15) when per-band fluxes are requested.
 template <bool BAND, typename FT>

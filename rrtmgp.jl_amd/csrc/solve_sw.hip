@@ -181,6 +181,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             struct Stream { FT tau_cum, dir_above, beta, delta; };
             Stream S{FT(0), dir_top, FT(0), FT(0)}, C{FT(0), dir_top, FT(0), FT(0)};
             MaskWalk<false> mw(m0, m1, nlay, sh.mask);  // top-down
+            if (RR_ACC_ATOMIC && !BAND)   // the layer loop ADDS into this wave's accumulators (wave_add_to)
+                for (int i = lane; i < nlev * NA; i += 64) acc[i] = FT(0);
             {
                 const FT s = seg_sum<BAND>(dir_top * amask);
                 if (writer) {
@@ -202,8 +204,13 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 t.delta = s_dn + Tdif * den * (t.delta + t.beta * s_up);
                 t.beta = beta_n;
 #ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
-                const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(t.delta * amask);
-                if (writer) { acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel; }
+                if (RR_ACC_ATOMIC && !BAND) {
+                    wave_add_to(&acc[k * NA + aoff + 2], dir_k * amask);
+                    wave_add_to(&acc[k * NA + aoff + 1], t.delta * amask);
+                } else {
+                    const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(t.delta * amask);
+                    if (writer) { acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel; }
+                }
 #endif
                 t.dir_above = dir_k;
             };
