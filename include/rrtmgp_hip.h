@@ -422,9 +422,13 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void
  *    as the pointers.  LwBCs.inc_flux, whose FASTEST dimension is ncol, is handed to the shards as
  *    2-D blocks (inc_flux_ld).  Not shardable in one call, rejected with RRTMGP_EUNSUPPORTED when
  *    ndev > 1: flux layout RRTMGP_LAYOUT_NCOL_NLEV (ncol fastest) and per-band fluxes.
- *  - Host arrays are page-locked on first use (hipHostRegister, cached per workspace by
- *    address and size, released by workspace_destroy) so that the per-shard uploads and
- *    downloads are true asynchronous DMA; RRTMGP_HIP_NO_HOST_REGISTER=1 turns this off.
+ *  - Host arrays of at least 32 MB are page-locked on first use (hipHostRegister; released by
+ *    workspace_destroy, or when 8 solves of the workspace have not used them) so that the per-shard
+ *    and per-chunk copies are true asynchronous DMA.  RRTMGP_HIP_HOST_REGISTER_MIN_BYTES changes
+ *    the floor, RRTMGP_HIP_NO_HOST_REGISTER=1 turns registration off.  Smaller arrays are NOT
+ *    registered: they live in the allocator's heap and share pages with unrelated objects, and a
+ *    page lock that the runtime takes and drops on such a neighbour unmaps the shared page under
+ *    a registration (GPU memory access fault).  From 32 MB on glibc always mmaps.
  */
 int rrtmgp_hip_gas_lookup_create_multi(const rrtmgp_gas_lookup_desc *desc, const int32_t *device_ids, int ndev,
                                        rrtmgp_lookup **out);

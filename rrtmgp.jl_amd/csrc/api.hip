@@ -1,5 +1,9 @@
 // api.hip — host side of the C ABI declared in include/rrtmgp_hip.h:
 // lookup re-layout + upload, workspaces, host<->HBM staging, solver dispatch.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -21,6 +25,22 @@ int set_error(int code, const std::string &msg) {
 
 const std::string &last_error_string() { return g_last_error; }
 
+// Debug aid (RRTMGP_HIP_BACKTRACE_ON_ABORT=1): the C call stack of an abort() — e.g. one raised inside the HIP runtime —
+// on stderr before the process dies.
+static void abort_backtrace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "rrtmgp_hip: SIGABRT, C call stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static const bool g_abort_hook = [] {
+    if (getenv("RRTMGP_HIP_BACKTRACE_ON_ABORT")) signal(SIGABRT, abort_backtrace);
+    return true;
+}();
+
 static std::atomic<int64_t> g_dev_allocs{0}, g_dev_frees{0}, g_host_regs{0};
 hipError_t rr_malloc(void **p, size_t bytes) {
     const hipError_t e = hipMalloc(p, bytes);
@@ -32,46 +52,113 @@ hipError_t rr_free(void *p) {
     return hipFree(p);
 }
 
-// Host arrays handed over with RRTMGP_MEM_HOST are page-locked the first time they are seen, so that the
+// Large host arrays handed over with RRTMGP_MEM_HOST are page-locked the first time they are seen, so that the
 // hipMemcpyAsync calls below are real asynchronous DMA (from pageable memory the runtime stages through its own
 // bounce buffers and the "asynchronous" copy blocks the host thread).  A host model keeps its state arrays for the
-// whole run, so this happens once per array: the registry is process-wide, keyed by address range, and a range
-// inside a registered one (a shard's or a chunk's slab of the same array) counts as registered.  Entries belong to
-// the workspace that made them and are released by its destroy.  Any failure (memory that cannot be registered, a
-// range straddling an earlier registration) leaves the array pageable: slower, still correct.
-struct PinEntry { size_t bytes; rrtmgp_workspace *owner; };
+// whole run, so this happens once per array: the registry is process-wide and keyed by address range.
+//
+// Only arrays of at least 32 MB are registered (RRTMGP_HIP_HOST_REGISTER_MIN_BYTES; RRTMGP_HIP_NO_HOST_REGISTER=1 = never).
+// hipHostRegister locks whole PAGES.  A smaller array comes from the allocator's heap and shares its first and last page
+// with unrelated objects; when the runtime later locks and unlocks one of those for a pageable copy of its own, it
+// unmaps the shared page under our registration, and the next DMA through it dies with "Memory access fault by GPU"
+// (seen with 100 KB numpy arrays: 4 of 24 runs of the test suite).  From 32 MB on glibc always mmaps (its dynamic
+// threshold never exceeds that), so the pages belong to the array alone.
+//
+// A registration can outlive its array (the caller frees the array and keeps the workspace).  Rules that keep a stale
+// one from ever being used or found half-way by the HIP runtime:
+//   * a request counts as registered only on an EXACT (address, size) match, or inside a range that the solving
+//     workspace (or its multi-device head) verified in its current registration pass: the slabs of shards and chunks;
+//   * before any copy from / to host memory, every other registration that overlaps the buffer is released;
+//   * a workspace releases what none of its last 8 solves touched, and everything when it is destroyed.
+struct PinEntry {
+    size_t bytes;
+    rrtmgp_workspace *owner;  // releases it (destroy, or 8 of its passes without a touch)
+    uint64_t last_used;       // the owner's pass counter at the last touch by the owner
+    // the workspace that matched it exactly most recently, and that workspace's pass: while that pass is current, its
+    // shards and chunks may use slabs INSIDE the range (two workspaces, e.g. LW and SW, share the caller's state arrays)
+    const rrtmgp_workspace *verified_by;
+    uint64_t verified_pass;
+};
 static std::mutex g_pin_mu;
 static std::map<const char *, PinEntry> g_pins;
+
+static void drop(std::map<const char *, PinEntry>::iterator &it) {
+    (void)hipHostUnregister(const_cast<char *>(it->first));
+    (void)hipGetLastError();
+    it = g_pins.erase(it);
+}
+// Releases every registration that overlaps [p, p + bytes) and is not valid for it; returns true when a valid one covers
+// the whole buffer.  `touch`: mark it used in the owner's current pass.  (Caller holds g_pin_mu.)
+static bool settle(const rrtmgp_workspace *ws, const char *p, size_t bytes, bool touch) {
+    bool covered = false;
+    auto it = g_pins.upper_bound(p);
+    if (it != g_pins.begin()) --it;
+    while (it != g_pins.end() && it->first < p + bytes) {
+        const char *a = it->first, *b = a + it->second.bytes;
+        if (b <= p) { ++it; continue; }
+        PinEntry &e = it->second;
+        const bool exact = a == p && e.bytes == bytes;
+        const bool mine = ws && e.verified_by && (e.verified_by == ws || e.verified_by == ws->head) &&
+                          e.verified_pass == e.verified_by->pin_pass;
+        if (exact || (a <= p && p + bytes <= b && mine)) {
+            covered = true;
+            if (touch && exact && ws) {
+                if (e.owner == ws) e.last_used = ws->pin_pass;
+                e.verified_by = ws;
+                e.verified_pass = ws->pin_pass;
+            }
+            ++it;
+        } else {
+            drop(it);
+        }
+    }
+    return covered;
+}
+void host_range_check(const rrtmgp_workspace *ws, const void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return;
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    if (!g_pins.empty()) (void)settle(ws, (const char *)ptr, bytes, false);
+}
+static size_t host_register_min() {
+    static const size_t v = getenv("RRTMGP_HIP_NO_HOST_REGISTER") ? ~size_t(0)
+                            : getenv("RRTMGP_HIP_HOST_REGISTER_MIN_BYTES") ? (size_t)atoll(getenv("RRTMGP_HIP_HOST_REGISTER_MIN_BYTES"))
+                                                                            : (size_t)32 << 20;
+    return v;
+}
 bool host_pin(rrtmgp_workspace *ws, const void *ptr, size_t bytes) {
-    static const bool off = getenv("RRTMGP_HIP_NO_HOST_REGISTER") != nullptr;
-    if (off || !ptr || bytes < (1u << 16)) return false;  // small arrays: not worth a registration
+    if (!ptr || !bytes) return false;
     const char *p = (const char *)ptr;
     std::lock_guard<std::mutex> lock(g_pin_mu);
-    auto it = g_pins.upper_bound(p);
-    if (it != g_pins.begin()) {
-        auto prev = std::prev(it);
-        if (p + bytes <= prev->first + prev->second.bytes) return true;   // inside a registered range
-        if (p < prev->first + prev->second.bytes) return false;           // straddles one
-    }
-    if (it != g_pins.end() && it->first < p + bytes) return false;        // would swallow a later one
-    if (g_pins.size() >= 1024) return false;
+    if (settle(ws, p, bytes, true)) return true;
+    if (bytes < host_register_min() || g_pins.size() >= 1024) return false;
     if (hipHostRegister(const_cast<char *>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     g_host_regs++;
-    g_pins.emplace(p, PinEntry{bytes, ws});
+    g_pins.emplace(p, PinEntry{bytes, ws, ws->pin_pass, ws, ws->pin_pass});
     return true;
+}
+// A registration pass of `ws` (one per host-array solve) begins: what it touches from here on is current.
+void host_pin_begin(rrtmgp_workspace *ws) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    ws->pin_pass++;
+}
+// ... and ends: registrations of `ws` that none of its last 8 passes touched belong to arrays the caller no longer
+// hands over — probably freed — and are released.
+void host_pin_sweep(rrtmgp_workspace *ws) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    for (auto it = g_pins.begin(); it != g_pins.end();) {
+        if (it->second.owner == ws && it->second.last_used + 8 < ws->pin_pass) drop(it);
+        else ++it;
+    }
 }
 void host_unpin_all(rrtmgp_workspace *ws) {
     std::lock_guard<std::mutex> lock(g_pin_mu);
     for (auto it = g_pins.begin(); it != g_pins.end();) {
-        if (it->second.owner == ws) {
-            (void)hipHostUnregister(const_cast<char *>(it->first));
-            it = g_pins.erase(it);
-        } else {
-            ++it;
-        }
+        if (it->second.verified_by == ws) it->second.verified_by = nullptr;
+        if (it->second.owner == ws) drop(it);
+        else ++it;
     }
 }
 
@@ -153,7 +240,10 @@ static int upload(rrtmgp_lookup *lk, const std::vector<T> &h, const T **out) {
     const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
     RR_HIP(rr_malloc(&d, bytes));
     lk->allocs.push_back(d);
-    if (!h.empty()) RR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!h.empty()) {
+        host_range_check(nullptr, h.data(), h.size() * sizeof(T));  // no stale registration under this buffer (host_pin)
+        RR_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
     *out = (const T *)d;
     return RRTMGP_OK;
 }
@@ -425,6 +515,7 @@ struct Stager {
             return RRTMGP_OK;
         }
         TRY(stage_ensure(ws, slot, bytes));
+        host_range_check(ws, p, bytes);  // no stale page-lock registration under this buffer (host_pin)
         if (!((keep >> slot) & 1)) RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
@@ -440,6 +531,7 @@ struct Stager {
             return RRTMGP_OK;
         }
         TRY(stage_ensure(ws, slot, width * height));
+        host_range_check(ws, p, spitch * (height - 1) + width);
         RR_HIP(hipMemcpy2DAsync(ws->stage[slot].ptr, width, p, spitch, width, height, hipMemcpyHostToDevice, copy_stream()));
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
@@ -457,6 +549,7 @@ struct Stager {
             return RRTMGP_OK;
         }
         TRY(stage_ensure(ws, slot, bytes));
+        host_range_check(ws, p, bytes);
         *outp = ws->stage[slot].ptr;
         backs.push_back({p, ws->stage[slot].ptr, bytes});
         return RRTMGP_OK;
@@ -475,6 +568,7 @@ struct Stager {
             return RRTMGP_OK;
         }
         TRY(stage_ensure(ws, slot, bytes));
+        host_range_check(ws, p, bytes);
         RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
         *outp = ws->stage[slot].ptr;
         backs.push_back({const_cast<void *>(p), ws->stage[slot].ptr, bytes});
@@ -834,20 +928,24 @@ template <typename FT>
 static int pin_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
                   int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
                   const rrtmgp_solve_opts *opts, size_t *need = nullptr) {
+    host_pin_begin(ws);
     Stager pin{ws, {}};
     pin.pin_only = true;
     const int rc = solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
     if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
+    host_pin_sweep(ws);
     return rc;
 }
 template <typename FT>
 static int pin_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
                   int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs, const rrtmgp_flux_out *flux,
                   const rrtmgp_solve_opts *opts, size_t *need = nullptr) {
+    host_pin_begin(ws);
     Stager pin{ws, {}};
     pin.pin_only = true;
     const int rc = solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
     if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
+    host_pin_sweep(ws);
     return rc;
 }
 

@@ -137,6 +137,8 @@ struct rrtmgp_workspace {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     int n_cu = 0;
+    rrtmgp_workspace *head = nullptr;  // shard of a multi-device workspace: its head
+    uint64_t pin_pass = 0;  // registration passes so far (host-array solves): ages this workspace's page-lock registrations
     // staging mirrors for host-memory callers, keyed by slot; the second set and the copy stream serve the
     // pipelined host path (column chunks: chunk c+1 is uploaded while chunk c is being solved)
     std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
@@ -181,6 +183,9 @@ hipError_t rr_malloc(void **p, size_t bytes);
 hipError_t rr_free(void *p);
 // page-lock a caller's host array once (process-wide registry, owner = ws); false = it stays pageable
 bool host_pin(rrtmgp_workspace *ws, const void *p, size_t bytes);
+void host_pin_begin(rrtmgp_workspace *ws);
+void host_pin_sweep(rrtmgp_workspace *ws);
+void host_range_check(const rrtmgp_workspace *ws, const void *p, size_t bytes);  // drops registrations that overlap [p, p + bytes) without containing it
 void host_unpin_all(rrtmgp_workspace *ws);
 
 // the replica of `lk` that lives on `device` (lk itself when it does), or nullptr

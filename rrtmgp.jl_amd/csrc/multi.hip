@@ -97,6 +97,7 @@ int rrtmgp_hip_workspace_create_multi(const int32_t *device_ids, int ndev, int64
             rrtmgp_hip_workspace_destroy(head);
             return set_error(rc, m);
         }
+        w->head = head;
         head->shards.push_back(w);
     }
     *out = head;
