@@ -54,3 +54,25 @@ def test_mcica_stream_host_function_matches_oracle():
     L = _lib.lib()
     for args in [(0, 1, 1, 0, 0), (2026, 77, 200, 1, 3), (2 ** 63 + 5, 10 ** 6, 256, 0, 17)]:
         assert L.rrtmgp_hip_mcica_uniform(*args) == O.mcica_uniform(*args)
+
+
+def test_header_is_plain_c_and_a_c_program_can_bind_it(tmp_path):
+    """The boundary is a C ABI: include/rrtmgp_hip.h must compile as C99 (and C++), and a program written in plain C
+    — what a `ccall` / cgo / FFI binding amounts to — links against the shared library and runs without a GPU:
+    struct sizes as the library reports them, the host-callable McICA stream, a loud status without a device."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "rrtmgp_hip.h")
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no C compiler")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr], check=True)
+    _lib.build()
+    libdir = os.path.dirname(_lib.SO_PATH)
+    exe = str(tmp_path / "c_consumer")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_consumer.c"), "-L" + libdir, "-lhip_rrtmgp",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 problem(s)" in r.stdout, r.stdout + r.stderr
