@@ -13,7 +13,8 @@ int main(void) {
     /* struct mirrors, in the library's numbering (rrtmgp_hip_abi_sizeof) */
     const size_t sizes[] = {sizeof(rrtmgp_minor_desc),        sizeof(rrtmgp_gas_lookup_desc), sizeof(rrtmgp_cloud_lookup_desc),
                             sizeof(rrtmgp_aerosol_lookup_desc), sizeof(rrtmgp_atmos_state),    sizeof(rrtmgp_lw_bcs),
-                            sizeof(rrtmgp_sw_bcs),            sizeof(rrtmgp_flux_out),        sizeof(rrtmgp_solve_opts)};
+                            sizeof(rrtmgp_sw_bcs),            sizeof(rrtmgp_flux_out),        sizeof(rrtmgp_solve_opts),
+                            sizeof(rrtmgp_gray_state),        sizeof(rrtmgp_params),          sizeof(rrtmgp_prepare_opts)};
     for (int i = 0; i < (int)(sizeof sizes / sizeof sizes[0]); i++)
         if (rrtmgp_hip_abi_sizeof(i) != (int)sizes[i]) {
             printf("struct %d: header says %zu bytes, library %d\n", i, sizes[i], rrtmgp_hip_abi_sizeof(i));
