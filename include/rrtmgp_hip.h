@@ -212,6 +212,9 @@ typedef struct rrtmgp_flux_out {
     void *band_flux_up;
     void *band_flux_dn;
     void *band_flux_net;
+    int64_t band_flux_ncol; /* columns of the band arrays' second dimension; 0 = ncol.  Larger: the arrays are a block of
+                             * columns inside wider (nlev, band_flux_ncol, nbnd) arrays — how the library hands
+                             * column ranges of them to shards and pipeline chunks */
     /* AllSkyRadiationWithClearSkyDiagnostics, src/api/update_fluxes.jl:39-65,101-128: the reference
      * solves twice (clear, then all-sky) and snapshots the first result.  When clear_flux_up is
      * non-NULL (clear_flux_dn / _net required with it; clear_flux_dn_dir for SW) and a cloud lookup
@@ -419,9 +422,10 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void
  *    shard so that the McICA stream stays keyed by the global column, and returns when every
  *    shard's results are in the caller's arrays.  The bits are those of a single launch.
  *  - Arrays must be host memory (RRTMGP_MEM_HOST) unless every shard is on the same device
- *    as the pointers.  LwBCs.inc_flux, whose FASTEST dimension is ncol, is handed to the shards as
- *    2-D blocks (inc_flux_ld).  Not shardable in one call, rejected with RRTMGP_EUNSUPPORTED when
- *    ndev > 1: flux layout RRTMGP_LAYOUT_NCOL_NLEV (ncol fastest) and per-band fluxes.
+ *    as the pointers.  The arrays whose column ranges are not contiguous slabs — LwBCs.inc_flux
+ *    (ncol fastest) and the per-band fluxes (ncol in the middle) — are handed to the shards as
+ *    strided blocks (inc_flux_ld, band_flux_ncol).  Not shardable in one call, rejected with
+ *    RRTMGP_EUNSUPPORTED when ndev > 1: the flux layout RRTMGP_LAYOUT_NCOL_NLEV (ncol fastest).
  *  - Host arrays of at least 32 MB are page-locked on first use (hipHostRegister; released by
  *    workspace_destroy, or when 8 solves of the workspace have not used them) so that the per-shard
  *    and per-chunk copies are true asynchronous DMA.  RRTMGP_HIP_HOST_REGISTER_MIN_BYTES changes

@@ -469,7 +469,7 @@ enum Slot {
 
 struct Stager {
     rrtmgp_workspace *ws;
-    struct Back { void *host; void *dev; size_t bytes; };
+    struct Back { void *host; void *dev; size_t bytes; size_t rows = 0, hpitch = 0; };  // rows > 0: `rows` pieces of `bytes`, hpitch apart at the host
     std::vector<Back> backs;
     hipStream_t cs = nullptr;  // stream of the copies; the workspace stream unless the pipelined host path says otherwise
     bool pin_only = false;     // registration pass over the caller's WHOLE host arrays: no copies, no device memory
@@ -554,6 +554,23 @@ struct Stager {
         backs.push_back({p, ws->stage[slot].ptr, bytes});
         return RRTMGP_OK;
     }
+    // output, HOST memory only: `height` pieces of `width` bytes, packed on the device, `dpitch` bytes apart at the host
+    int out2d(int slot, void *p, size_t width, size_t height, size_t dpitch, void **outp) {
+        if (!p) { *outp = nullptr; return RRTMGP_OK; }
+        if (pin_only) { need += al(width * height); *outp = nullptr; return RRTMGP_OK; }
+        if (packed) {
+            size_t o;
+            TRY(take(width * height, false, true, &o));
+            *outp = ws->bounce_d + o;
+            backs.push_back({p, ws->bounce_d + o, width, height, dpitch});
+            return RRTMGP_OK;
+        }
+        TRY(stage_ensure(ws, slot, width * height));
+        host_range_check(ws, p, dpitch * (height - 1) + width);
+        *outp = ws->stage[slot].ptr;
+        backs.push_back({p, ws->stage[slot].ptr, width, height, dpitch});
+        return RRTMGP_OK;
+    }
     // read AND written: staged in, copied back by finish()
     int inout(int mem, int slot, const void *p, size_t bytes, void **outp) {
         if (!p) { *outp = nullptr; return RRTMGP_OK; }
@@ -579,17 +596,28 @@ struct Stager {
             if (out_hi > out_lo)
                 RR_HIP(hipMemcpyAsync(ws->bounce_h + out_lo, ws->bounce_d + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, ws->stream));
             RR_HIP(hipStreamSynchronize(ws->stream));
-            for (auto &b : backs) memcpy(b.host, ws->bounce_h + ((char *)b.dev - ws->bounce_d), b.bytes);
+            for (auto &b : backs) {
+                const char *src = ws->bounce_h + ((char *)b.dev - ws->bounce_d);
+                if (!b.rows) memcpy(b.host, src, b.bytes);
+                else for (size_t r = 0; r < b.rows; r++) memcpy((char *)b.host + r * b.hpitch, src + r * b.bytes, b.bytes);
+            }
             return RRTMGP_OK;
         }
         if (backs.empty()) return RRTMGP_OK;
-        for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ws->stream));
+        TRY(issue_backs(ws->stream));
         RR_HIP(hipStreamSynchronize(ws->stream));
+        return RRTMGP_OK;
+    }
+    int issue_backs(hipStream_t s) {
+        for (auto &b : backs) {
+            if (!b.rows) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s));
+            else RR_HIP(hipMemcpy2DAsync(b.host, b.hpitch, b.dev, b.bytes, b.bytes, b.rows, hipMemcpyDeviceToHost, s));
+        }
         return RRTMGP_OK;
     }
     // copies back on the copy stream, no synchronisation (pipelined host path)
     int copy_back() {
-        for (auto &b : backs) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, copy_stream()));
+        TRY(issue_backs(copy_stream()));
         backs.clear();
         return RRTMGP_OK;
     }
@@ -658,12 +686,25 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
     if (sw) TRY(st.out(f->mem, S_FLUX_DIR, f->flux_dn_dir, bytes, (void **)&d.dir));
     d.layout = f->layout;
     d.band_up = d.band_dn = d.band_net = nullptr;
+    d.band_ncol = (int)ncol;
     if (f->band_flux_up || f->band_flux_dn || f->band_flux_net) {
         RR_CHECK(nbnd > 0, "per-band fluxes are only available from the two-stream, non-gray solvers");
         RR_CHECK(f->band_flux_up && f->band_flux_dn, "per-band fluxes: band_flux_up and band_flux_dn go together");
-        TRY(st.out(f->mem, S_BAND_UP, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
-        TRY(st.out(f->mem, S_BAND_DN, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
-        if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
+        // (nlev, ncol, nbnd): a column range of wider arrays is nbnd blocks of nlev * ncol values, band_flux_ncol * nlev apart
+        const size_t bcols = f->band_flux_ncol > 0 ? (size_t)f->band_flux_ncol : ncol;
+        RR_CHECK(bcols >= ncol, "band_flux_ncol is smaller than ncol");
+        d.band_ncol = (int)ncol;  // host blocks are packed in the staging buffers and strided on the way home
+        if (bcols != ncol && f->mem == RRTMGP_MEM_HOST) {
+            const size_t w = bytes, pitch = bcols * nlev * sizeof(FT);
+            TRY(st.out2d(S_BAND_UP, f->band_flux_up, w, nbnd, pitch, (void **)&d.band_up));
+            TRY(st.out2d(S_BAND_DN, f->band_flux_dn, w, nbnd, pitch, (void **)&d.band_dn));
+            if (f->band_flux_net) TRY(st.out2d(S_BAND_NET, f->band_flux_net, w, nbnd, pitch, (void **)&d.band_net));
+        } else {
+            if (f->mem == RRTMGP_MEM_DEVICE) d.band_ncol = (int)bcols;
+            TRY(st.out(f->mem, S_BAND_UP, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
+            TRY(st.out(f->mem, S_BAND_DN, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
+            if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
+        }
     }
     d.clear_up = d.clear_dn = d.clear_net = d.clear_dir = nullptr;
     if (f->clear_flux_up || f->clear_flux_dn || f->clear_flux_net || f->clear_flux_dn_dir) {
@@ -797,9 +838,14 @@ static void slice_state(rrtmgp_atmos_state &a, const ColumnSlice &s, size_t nc) 
     a.aero_size = s.adv(a.aero_size, RRTMGP_N_AEROSOLS * nlay); a.aero_mass = s.adv(a.aero_mass, RRTMGP_N_AEROSOLS * nlay);
     a.aod_sw_ext = s.adv(a.aod_sw_ext, 1); a.aod_sw_sca = s.adv(a.aod_sw_sca, 1);
 }
-static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev) {
+static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev, size_t ncol_total) {
     f.flux_up = s.adv(f.flux_up, nlev); f.flux_dn = s.adv(f.flux_dn, nlev); f.flux_net = s.adv(f.flux_net, nlev);
     f.flux_dn_dir = s.adv(f.flux_dn_dir, nlev);
+    if (f.band_flux_up || f.band_flux_dn || f.band_flux_net) {   // (nlev, ncol, nbnd): the block starts c0 columns in
+        if (f.band_flux_ncol <= 0) f.band_flux_ncol = (int64_t)ncol_total;
+        f.band_flux_up = s.adv(f.band_flux_up, nlev); f.band_flux_dn = s.adv(f.band_flux_dn, nlev);
+        f.band_flux_net = s.adv(f.band_flux_net, nlev);
+    }
     f.clear_flux_up = s.adv(f.clear_flux_up, nlev); f.clear_flux_dn = s.adv(f.clear_flux_dn, nlev);
     f.clear_flux_net = s.adv(f.clear_flux_net, nlev); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, nlev);
     o.metric_scaling = s.adv(o.metric_scaling, nlev);
@@ -837,8 +883,6 @@ static int check_multi(const rrtmgp_workspace *ws, int state_mem, int bcs_mem, c
     if (any_dev && !one_device) return set_error(RRTMGP_EINVAL, "a workspace spanning several devices needs host arrays");
     if (flux && flux->layout != RRTMGP_LAYOUT_NLEV_NCOL)
         return set_error(RRTMGP_EUNSUPPORTED, "multi-shard solves need the (nlev, ncol) flux layout: ncol must be the slowest dimension");
-    if (flux && (flux->band_flux_up || flux->band_flux_dn || flux->band_flux_net))
-        return set_error(RRTMGP_EUNSUPPORTED, "per-band fluxes cannot be sharded in one call");
     return RRTMGP_OK;
 }
 
@@ -847,7 +891,7 @@ static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, con
     static const bool off = getenv("RRTMGP_HIP_NO_HOST_PIPELINE") != nullptr;
     if (off || !as || !flux) return false;
     if (as->mem != RRTMGP_MEM_HOST || bcs_mem != RRTMGP_MEM_HOST || flux->mem != RRTMGP_MEM_HOST) return false;
-    if (flux->layout != RRTMGP_LAYOUT_NLEV_NCOL || flux->band_flux_up || flux->band_flux_dn || flux->band_flux_net) return false;
+    if (flux->layout != RRTMGP_LAYOUT_NLEV_NCOL) return false;
     if (opts && opts->metric_scaling && opts->metric_mem != RRTMGP_MEM_HOST) return false;
     return as->ncol >= 16384;
 }
@@ -887,7 +931,7 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
         rrtmgp_solve_opts o{};
         if (opts) o = *opts; else o.n_gauss_angles = 1;
         slice_state(a, sl, c1 - c0);
-        slice_flux(f, o, sl, nlev);
+        slice_flux(f, o, sl, nlev, ncol);
         std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
         Stager st{ws, {}};
         st.cs = ws->copy_stream;
@@ -1316,7 +1360,7 @@ static int multi_spectral(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, const 
         rrtmgp_solve_opts o{};
         if (opts) o = *opts; else o.n_gauss_angles = 1;
         slice_state(a, sl, nc);
-        slice_flux(f, o, sl, nlev);
+        slice_flux(f, o, sl, nlev, (size_t)as->ncol);
         slice_bcs(b, sl);
         const rrtmgp_lookup *g = lookup_on(gas, sw->device), *c = lookup_on(cld, sw->device), *ae = lookup_on(aero, sw->device);
         if (!g || (cld && !c) || (aero && !ae))
@@ -1429,7 +1473,7 @@ static int multi_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const B
         rrtmgp_solve_opts o{};
         if (opts) o = *opts; else o.n_gauss_angles = 1;
         slice_gray(g, sl, nc);
-        slice_flux(f, o, sl, nlev);
+        slice_flux(f, o, sl, nlev, (size_t)gs->ncol);
         slice_bcs(b, sl);
         return call(sw, &g, &b, &f, &o);
     });

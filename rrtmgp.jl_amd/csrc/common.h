@@ -93,7 +93,8 @@ struct DevFlux {
     FT *up, *dn, *net, *dir;
     int layout;
     const FT *metric;  // (nlev, ncol) or nullptr
-    FT *band_up, *band_dn, *band_net;  // optional FluxBand (nlev, ncol, nbnd); band_net may be null on its own
+    FT *band_up, *band_dn, *band_net;  // optional FluxBand (nlev, band_ncol, nbnd); band_net may be null on its own
+    int band_ncol;                     // second dimension of the band arrays as the kernel writes them (>= ncol)
     FT *clear_up, *clear_dn, *clear_net, *clear_dir;  // optional clear-sky diagnostic (same layout as up/dn/net/dir)
 };
 

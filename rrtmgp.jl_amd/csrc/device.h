@@ -1222,7 +1222,7 @@ __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT, C
                 const FT m = fl.metric[(size_t)nlev * col + lev];
                 up *= m; dn *= m;
             }
-            const size_t o = ((size_t)b * ncol + col) * nlev + lev;
+            const size_t o = ((size_t)b * fl.band_ncol + col) * nlev + lev;
             fl.band_up[o] = up; fl.band_dn[o] = dn;
             if (fl.band_net) fl.band_net[o] = up - dn;
         }

@@ -441,6 +441,28 @@ def test_wave_sum16_device_unit_test(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_host_pipeline_with_band_fluxes_and_incident_flux(tables32):
+    """The two arrays whose column ranges are not contiguous slabs — LwBCs.inc_flux (ncol, ngpt) and FluxBand
+    (nlev, ncol, nbnd) — travel through the pipelined host path as strided blocks: same bits as one device-resident
+    launch."""
+    import torch
+    t = tables32
+    ncol, nlay = 33_333, 8       # 4 chunks, the last one shorter
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=7, night_fraction=0.2, random_cld_frac=True,
+                                 inc_flux_ngpt=t["lw"].n_gpt)
+    nb = t["lw"].n_bnd
+    h = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb, n_bnd_band_flux=nb)
+    rte.solve_lw(h, as_, t["lw"], t["cld_lw"], seed=3)
+    dev = "cuda:0"
+    d = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb.to_device(dev), flux_device=dev, n_bnd_band_flux=nb)
+    rte.solve_lw(d, as_.to_device(dev), t["lw"], t["cld_lw"], seed=3)
+    d.ws.synchronize(); torch.cuda.synchronize()
+    for n in LWN:
+        np.testing.assert_array_equal(getattr(h.flux, n), getattr(d.flux.to_host(), n))
+        np.testing.assert_array_equal(getattr(h.band_flux, n), getattr(d.band_flux.to_host(), n))
+    assert np.abs(h.flux.as_nlev_ncol("flux_dn")[-1] - lb.inc_flux.sum(axis=1)).max() < 1e-2   # TOA dn = incident flux
+
+
 def test_host_pipeline_matches_device_resident_solve(tables32):
     """Large host-memory solves are cut into column chunks whose uploads overlap the previous chunk's
     kernel (api.hip, "pipelined host path").  Same bits as the single-launch device-resident solve,

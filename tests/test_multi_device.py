@@ -145,6 +145,26 @@ def test_incident_flux_block_of_a_wider_array_host_and_device(tables64):
         np.testing.assert_array_equal(got.as_nlev_ncol(n), ref.as_nlev_ncol(n))
 
 
+def test_band_fluxes_are_sharded_as_blocks_of_columns(tables64):
+    """FluxBand is (nlev, ncol, nbnd): a shard's columns are nbnd blocks inside the caller's arrays.  The library hands
+    them around with `band_flux_ncol` and writes them home with strided copies: the bits of the single launch."""
+    t = tables64
+    as_, lb, sb = S.make_columns(13, 24, np.float64, seed=6, random_cld_frac=True, night_fraction=0.2)
+    nlay, ncol = as_.dims
+    for sw in (False, True):
+        r = "sw" if sw else "lw"
+        cls, solve, bcs = (rte.TwoStreamSWRTE, rte.solve_sw, sb) if sw else (rte.TwoStreamLWRTE, rte.solve_lw, lb)
+        nb = t[r].n_bnd
+        one = cls(ncol, nlay, np.float64, bcs, n_bnd_band_flux=nb)
+        solve(one, as_, t[r], t["cld_" + r], seed=8)
+        ids = [0, 0, 0]
+        many = cls(ncol, nlay, np.float64, bcs, n_bnd_band_flux=nb, workspace=rte.Workspace(ncol, nlay, np.float64, ids))
+        solve(many, as_, rte.DeviceLookup(t[r], ids), rte.DeviceLookup(t["cld_" + r], ids), seed=8)
+        for n in ("flux_up", "flux_dn", "flux_net"):
+            np.testing.assert_array_equal(getattr(many.band_flux, n), getattr(one.band_flux, n))
+            np.testing.assert_array_equal(many.flux.as_nlev_ncol(n), one.flux.as_nlev_ncol(n))
+
+
 def test_what_cannot_be_sharded_is_rejected_loudly(tables64):
     t = tables64
     as_, lb, sb = S.make_columns(8, 16, np.float64, seed=2, inc_flux_ngpt=t["lw"].n_gpt)
@@ -154,8 +174,6 @@ def test_what_cannot_be_sharded_is_rejected_loudly(tables64):
     lb2 = LwBCs(sfc_emis=lb.sfc_emis, inc_flux=None)
     with pytest.raises(_lib.RRTMGPHipError, match="layout"):
         rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb2, workspace=ws, layout=_abi.LAYOUT_NCOL_NLEV), as_, dl)
-    with pytest.raises(_lib.RRTMGPHipError, match="per-band"):
-        rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb2, workspace=ws, n_bnd_band_flux=t["lw"].n_bnd), as_, dl)
     with pytest.raises(_lib.RRTMGPHipError):   # more shards than columns
         rte.Workspace(1, nlay, np.float64, [0, 0])
     with pytest.raises(_lib.RRTMGPHipError):   # no such device
