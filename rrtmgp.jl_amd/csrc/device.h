@@ -1079,6 +1079,13 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
 // The layer loops visit the layers in order, so the mask is walked instead of indexed: one shift and one test per
 // layer (the 64-bit variable shift + select of mask_bit costs six VALU instructions).  UP: layers 0, 1, 2, ... (bit 0
 // is the current layer, shift right); otherwise nlay-1, nlay-2, ... (bit 63 is the current layer, shift left).
+// The word switch happens once per 64 layers: as a real (wave-uniform) branch it costs the scalar compare that is there
+// anyway; if-converted it is two v_cndmask_b32 in every layer.  The empty asm keeps the compiler from if-converting.
+#ifndef RR_EXP_REFILL_SELECT
+#define RR_REFILL_BRANCH() asm volatile("" ::: "memory")
+#else
+#define RR_REFILL_BRANCH() (void)0
+#endif
 template <bool UP>
 struct MaskWalk {
     uint64_t cur, other;
@@ -1114,11 +1121,11 @@ struct MaskWalk {
         if (UP) {
             b = (unsigned)cur & 1u;
             cur >>= 1;
-            if ((kq & 63) == 63) cur = other;
+            if ((kq & 63) == 63) { RR_REFILL_BRANCH(); cur = other; }
         } else {
             b = (long long)cur < 0;
             cur <<= 1;
-            if ((kq & 63) == 0) cur = other;
+            if ((kq & 63) == 0) { RR_REFILL_BRANCH(); cur = other; }
         }
         return b;
     }
