@@ -226,6 +226,8 @@ typedef struct rrtmgp_flux_out {
     void *clear_flux_dn;
     void *clear_flux_net;
     void *clear_flux_dn_dir;
+    int64_t flux_ncol; /* RRTMGP_LAYOUT_NCOL_NLEV only: columns of the first dimension of the (clear_)flux_* arrays; 0 = ncol.
+                        * Larger: the arrays are a block of columns inside wider (flux_ncol, nlev) arrays (shards, chunks) */
 } rrtmgp_flux_out;
 
 /* Per-call options. */
@@ -424,8 +426,8 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void
  *  - Arrays must be host memory (RRTMGP_MEM_HOST) unless every shard is on the same device
  *    as the pointers.  The arrays whose column ranges are not contiguous slabs — LwBCs.inc_flux
  *    (ncol fastest) and the per-band fluxes (ncol in the middle) — are handed to the shards as
- *    strided blocks (inc_flux_ld, band_flux_ncol).  Not shardable in one call, rejected with
- *    RRTMGP_EUNSUPPORTED when ndev > 1: the flux layout RRTMGP_LAYOUT_NCOL_NLEV (ncol fastest).
+ *    strided blocks (inc_flux_ld, band_flux_ncol), and so are fluxes in the RRTMGP_LAYOUT_NCOL_NLEV
+ *    layout (flux_ncol).
  *  - Host arrays of at least 32 MB are page-locked on first use (hipHostRegister; released by
  *    workspace_destroy, or when 8 solves of the workspace have not used them) so that the per-shard
  *    and per-chunk copies are true asynchronous DMA.  RRTMGP_HIP_HOST_REGISTER_MIN_BYTES changes

@@ -69,7 +69,8 @@ class SwBcs(C.Structure):
 class FluxOut(C.Structure):
     _fields_ = [("mem", i32), ("layout", i32), ("flux_up", vp), ("flux_dn", vp), ("flux_net", vp),
                 ("flux_dn_dir", vp), ("band_flux_up", vp), ("band_flux_dn", vp), ("band_flux_net", vp),
-                ("band_flux_ncol", i64), ("clear_flux_up", vp), ("clear_flux_dn", vp), ("clear_flux_net", vp), ("clear_flux_dn_dir", vp)]
+                ("band_flux_ncol", i64), ("clear_flux_up", vp), ("clear_flux_dn", vp), ("clear_flux_net", vp), ("clear_flux_dn_dir", vp),
+                ("flux_ncol", i64)]
 
 
 class SolveOpts(C.Structure):

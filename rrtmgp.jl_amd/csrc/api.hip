@@ -679,11 +679,20 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
     RR_CHECK(f && f->flux_up && f->flux_dn && f->flux_net, "flux outputs: missing array");
     RR_CHECK(f->layout == RRTMGP_LAYOUT_NCOL_NLEV || f->layout == RRTMGP_LAYOUT_NLEV_NCOL, "bad flux layout");
     const size_t bytes = ncol * nlev * sizeof(FT);
-    TRY(st.out(f->mem, S_FLUX_UP, f->flux_up, bytes, (void **)&d.up));
-    TRY(st.out(f->mem, S_FLUX_DN, f->flux_dn, bytes, (void **)&d.dn));
-    TRY(st.out(f->mem, S_FLUX_NET, f->flux_net, bytes, (void **)&d.net));
+    // (ncol, nlev) fluxes: a column range of wider arrays is nlev rows of ncol values, flux_ncol apart
+    const size_t fcols = f->layout == RRTMGP_LAYOUT_NCOL_NLEV && f->flux_ncol > 0 ? (size_t)f->flux_ncol : ncol;
+    RR_CHECK(fcols >= ncol, "flux_ncol is smaller than ncol");
+    const bool strided = fcols != ncol && f->mem == RRTMGP_MEM_HOST;  // packed on the device, strided on the way home
+    d.ld = f->mem == RRTMGP_MEM_DEVICE ? (int)fcols : (int)ncol;
+    auto flux_out = [&](int slot, void *p, FT **dev) -> int {
+        if (strided) return st.out2d(slot, p, ncol * sizeof(FT), nlev, fcols * sizeof(FT), (void **)dev);
+        return st.out(f->mem, slot, p, bytes, (void **)dev);
+    };
+    TRY(flux_out(S_FLUX_UP, f->flux_up, &d.up));
+    TRY(flux_out(S_FLUX_DN, f->flux_dn, &d.dn));
+    TRY(flux_out(S_FLUX_NET, f->flux_net, &d.net));
     d.dir = nullptr;
-    if (sw) TRY(st.out(f->mem, S_FLUX_DIR, f->flux_dn_dir, bytes, (void **)&d.dir));
+    if (sw) TRY(flux_out(S_FLUX_DIR, f->flux_dn_dir, &d.dir));
     d.layout = f->layout;
     d.band_up = d.band_dn = d.band_net = nullptr;
     d.band_ncol = (int)ncol;
@@ -711,10 +720,10 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
         RR_CHECK(nbnd > 0, "the clear-sky diagnostic is only available from the two-stream, non-gray solvers");
         RR_CHECK(f->clear_flux_up && f->clear_flux_dn && f->clear_flux_net && (!sw || f->clear_flux_dn_dir),
                  "clear-sky diagnostic: clear_flux_up / _dn / _net (and _dn_dir for SW) go together");
-        TRY(st.out(f->mem, S_CLR_UP, f->clear_flux_up, bytes, (void **)&d.clear_up));
-        TRY(st.out(f->mem, S_CLR_DN, f->clear_flux_dn, bytes, (void **)&d.clear_dn));
-        TRY(st.out(f->mem, S_CLR_NET, f->clear_flux_net, bytes, (void **)&d.clear_net));
-        if (sw) TRY(st.out(f->mem, S_CLR_DIR, f->clear_flux_dn_dir, bytes, (void **)&d.clear_dir));
+        TRY(flux_out(S_CLR_UP, f->clear_flux_up, &d.clear_up));
+        TRY(flux_out(S_CLR_DN, f->clear_flux_dn, &d.clear_dn));
+        TRY(flux_out(S_CLR_NET, f->clear_flux_net, &d.clear_net));
+        if (sw) TRY(flux_out(S_CLR_DIR, f->clear_flux_dn_dir, &d.clear_dir));
     }
     d.metric = nullptr;
     if (opts && opts->metric_scaling)
@@ -839,15 +848,22 @@ static void slice_state(rrtmgp_atmos_state &a, const ColumnSlice &s, size_t nc) 
     a.aod_sw_ext = s.adv(a.aod_sw_ext, 1); a.aod_sw_sca = s.adv(a.aod_sw_sca, 1);
 }
 static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev, size_t ncol_total) {
-    f.flux_up = s.adv(f.flux_up, nlev); f.flux_dn = s.adv(f.flux_dn, nlev); f.flux_net = s.adv(f.flux_net, nlev);
-    f.flux_dn_dir = s.adv(f.flux_dn_dir, nlev);
+    // (nlev, ncol): a contiguous slab, nlev values per column; (ncol, nlev): the block starts c0 elements in and keeps
+    // the row length of the whole array
+    size_t per_col = nlev;
+    if (f.layout == RRTMGP_LAYOUT_NCOL_NLEV) {
+        per_col = 1;
+        if (f.flux_ncol <= 0) f.flux_ncol = (int64_t)ncol_total;
+    }
+    f.flux_up = s.adv(f.flux_up, per_col); f.flux_dn = s.adv(f.flux_dn, per_col); f.flux_net = s.adv(f.flux_net, per_col);
+    f.flux_dn_dir = s.adv(f.flux_dn_dir, per_col);
     if (f.band_flux_up || f.band_flux_dn || f.band_flux_net) {   // (nlev, ncol, nbnd): the block starts c0 columns in
         if (f.band_flux_ncol <= 0) f.band_flux_ncol = (int64_t)ncol_total;
         f.band_flux_up = s.adv(f.band_flux_up, nlev); f.band_flux_dn = s.adv(f.band_flux_dn, nlev);
         f.band_flux_net = s.adv(f.band_flux_net, nlev);
     }
-    f.clear_flux_up = s.adv(f.clear_flux_up, nlev); f.clear_flux_dn = s.adv(f.clear_flux_dn, nlev);
-    f.clear_flux_net = s.adv(f.clear_flux_net, nlev); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, nlev);
+    f.clear_flux_up = s.adv(f.clear_flux_up, per_col); f.clear_flux_dn = s.adv(f.clear_flux_dn, per_col);
+    f.clear_flux_net = s.adv(f.clear_flux_net, per_col); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, per_col);
     o.metric_scaling = s.adv(o.metric_scaling, nlev);
     o.col_offset += (int64_t)s.c0;
 }
@@ -881,8 +897,6 @@ static int check_multi(const rrtmgp_workspace *ws, int state_mem, int bcs_mem, c
     const bool any_dev = state_mem == RRTMGP_MEM_DEVICE || bcs_mem == RRTMGP_MEM_DEVICE || (flux && flux->mem == RRTMGP_MEM_DEVICE) ||
                          (opts && opts->metric_scaling && opts->metric_mem == RRTMGP_MEM_DEVICE);
     if (any_dev && !one_device) return set_error(RRTMGP_EINVAL, "a workspace spanning several devices needs host arrays");
-    if (flux && flux->layout != RRTMGP_LAYOUT_NLEV_NCOL)
-        return set_error(RRTMGP_EUNSUPPORTED, "multi-shard solves need the (nlev, ncol) flux layout: ncol must be the slowest dimension");
     return RRTMGP_OK;
 }
 
@@ -891,7 +905,6 @@ static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, con
     static const bool off = getenv("RRTMGP_HIP_NO_HOST_PIPELINE") != nullptr;
     if (off || !as || !flux) return false;
     if (as->mem != RRTMGP_MEM_HOST || bcs_mem != RRTMGP_MEM_HOST || flux->mem != RRTMGP_MEM_HOST) return false;
-    if (flux->layout != RRTMGP_LAYOUT_NLEV_NCOL) return false;
     if (opts && opts->metric_scaling && opts->metric_mem != RRTMGP_MEM_HOST) return false;
     return as->ncol >= 16384;
 }

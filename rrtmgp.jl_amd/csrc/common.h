@@ -92,6 +92,7 @@ template <typename FT>
 struct DevFlux {
     FT *up, *dn, *net, *dir;
     int layout;
+    int ld;  // RRTMGP_LAYOUT_NCOL_NLEV: elements between consecutive levels of the flux arrays as the kernel writes them (>= ncol)
     const FT *metric;  // (nlev, ncol) or nullptr
     FT *band_up, *band_dn, *band_net;  // optional FluxBand (nlev, band_ncol, nbnd); band_net may be null on its own
     int band_ncol;                     // second dimension of the band arrays as the kernel writes them (>= ncol)

@@ -1202,7 +1202,7 @@ __device__ inline void store_column(const DevFlux<FT> &fl, const ColShared<FT, C
             const FT m = fl.metric[(size_t)nlev * col + lev];
             up *= m; dn *= m; net *= m; dir *= m;
         }
-        const size_t o = fl.layout == RRTMGP_LAYOUT_NCOL_NLEV ? (size_t)col + (size_t)ncol * lev
+        const size_t o = fl.layout == RRTMGP_LAYOUT_NCOL_NLEV ? (size_t)col + (size_t)fl.ld * lev
                                                                : (size_t)lev + (size_t)nlev * col;
         if (set == 0) {
             fl.up[o] = up; fl.dn[o] = dn; fl.net[o] = net;

@@ -42,7 +42,7 @@ __device__ __forceinline__ void put(const DevFlux<FT> &fl, int col, int ncol, in
         const FT m = fl.metric[(size_t)nlev * col + lev];
         up *= m; dn *= m; net *= m; dir *= m;
     }
-    const size_t o = fl.layout == RRTMGP_LAYOUT_NCOL_NLEV ? (size_t)col + (size_t)ncol * lev : (size_t)lev + (size_t)nlev * col;
+    const size_t o = fl.layout == RRTMGP_LAYOUT_NCOL_NLEV ? (size_t)col + (size_t)fl.ld * lev : (size_t)lev + (size_t)nlev * col;
     fl.up[o] = up; fl.dn[o] = dn; fl.net[o] = net;
     if (has_dir && fl.dir) fl.dir[o] = dir;
 }

@@ -461,6 +461,14 @@ def test_host_pipeline_with_band_fluxes_and_incident_flux(tables32):
         np.testing.assert_array_equal(getattr(h.flux, n), getattr(d.flux.to_host(), n))
         np.testing.assert_array_equal(getattr(h.band_flux, n), getattr(d.band_flux.to_host(), n))
     assert np.abs(h.flux.as_nlev_ncol("flux_dn")[-1] - lb.inc_flux.sum(axis=1)).max() < 1e-2   # TOA dn = incident flux
+    # ... and so do fluxes in the (ncol, nlev) layout: every chunk writes nlev strided rows of the caller's arrays
+    # (compared with the same kernel variant: the per-band variant sums the g-points in another order)
+    h1 = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
+    h2 = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb, layout=_abi.LAYOUT_NCOL_NLEV)
+    rte.solve_lw(h1, as_, t["lw"], t["cld_lw"], seed=3)
+    rte.solve_lw(h2, as_, t["lw"], t["cld_lw"], seed=3)
+    for n in LWN:
+        np.testing.assert_array_equal(h2.flux.as_nlev_ncol(n), h1.flux.as_nlev_ncol(n))
 
 
 def test_host_pipeline_matches_device_resident_solve(tables32):

@@ -165,15 +165,31 @@ def test_band_fluxes_are_sharded_as_blocks_of_columns(tables64):
             np.testing.assert_array_equal(many.flux.as_nlev_ncol(n), one.flux.as_nlev_ncol(n))
 
 
+def test_ncol_fastest_fluxes_are_sharded_as_strided_blocks(tables64):
+    """Fluxes in the (ncol, nlev) layout (what FluxLW holds on a device array type): a shard's columns are nlev rows of
+    the caller's arrays (`flux_ncol`); same numbers as the single launch, and as the (nlev, ncol) layout transposed."""
+    t = tables64
+    as_, lb, sb = S.make_columns(11, 16, np.float64, seed=9, random_cld_frac=True, night_fraction=0.2)
+    nlay, ncol = as_.dims
+    for sw in (False, True):
+        r = "sw" if sw else "lw"
+        cls, solve, bcs, names = (rte.TwoStreamSWRTE, rte.solve_sw, sb, SWN) if sw else (rte.TwoStreamLWRTE, rte.solve_lw, lb, LWN)
+        ref = solve(cls(ncol, nlay, np.float64, bcs), as_, t[r], t["cld_" + r], seed=8)
+        ids = [0, 0, 0]
+        many = solve(cls(ncol, nlay, np.float64, bcs, workspace=rte.Workspace(ncol, nlay, np.float64, ids),
+                         layout=_abi.LAYOUT_NCOL_NLEV),
+                     as_, rte.DeviceLookup(t[r], ids), rte.DeviceLookup(t["cld_" + r], ids), seed=8)
+        for n in names:
+            assert getattr(many, n).shape == (ncol, nlay + 1)
+            np.testing.assert_array_equal(many.as_nlev_ncol(n), ref.as_nlev_ncol(n))
+
+
 def test_what_cannot_be_sharded_is_rejected_loudly(tables64):
     t = tables64
     as_, lb, sb = S.make_columns(8, 16, np.float64, seed=2, inc_flux_ngpt=t["lw"].n_gpt)
     nlay, ncol = as_.dims
     ws = rte.Workspace(ncol, nlay, np.float64, [0, 0])
-    dl = rte.DeviceLookup(t["lw"], [0, 0])
     lb2 = LwBCs(sfc_emis=lb.sfc_emis, inc_flux=None)
-    with pytest.raises(_lib.RRTMGPHipError, match="layout"):
-        rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb2, workspace=ws, layout=_abi.LAYOUT_NCOL_NLEV), as_, dl)
     with pytest.raises(_lib.RRTMGPHipError):   # more shards than columns
         rte.Workspace(1, nlay, np.float64, [0, 0])
     with pytest.raises(_lib.RRTMGPHipError):   # no such device
