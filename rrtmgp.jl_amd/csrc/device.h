@@ -454,6 +454,12 @@ __device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDim
                                       const DevCld<FT> *cld, const DevAero<FT> *aero, const DevState<FT> &as, int col) {
     const int nlay = d.nlay, nlev = d.nlev, tid = threadIdx.x, nt = blockDim.x;
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
+#ifdef RR_EXP_PREP_SAME_LANES
+    const int tid2 = tid;
+#else
+    // thread index rotated by one wavefront: the loops after the layer records start on the wavefronts that have none
+    const int tid2 = nt > 64 ? (tid >= 64 ? tid - 64 : tid + nt - 64) : tid;
+#endif
     for (int k = tid; k < nlay; k += nt) {
         const FT col_dry = ld[4 * k + 0], p = ld[4 * k + 1], t = ld[4 * k + 2];
         LayerRec<FT> rec;
@@ -510,11 +516,12 @@ __device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDim
     // gas table: row ig (1-based gas index), row 0 = 1 (get_vmr, VolumeMixingRatios.jl:91-129)
     if (as.vmr_kind == RRTMGP_VMR_GM) {
         // only rows 1 (h2o) and 3 (o3) depend on the layer; the others repeat the well-mixed vector (LDS copy)
-        for (int i = tid; i < d.ngas1 * nlay; i += nt) {
+        // (the first wavefront is busy with the layer records above: the other wavefronts take these two loops first)
+        for (int i = tid2; i < d.ngas1 * nlay; i += nt) {
             const int ig = i / nlay;
             if (ig != 1 && ig != 3) sh.vmr[i] = sh.tab_vmr_gm[ig];
         }
-        for (int k = tid; k < 2 * nlay; k += nt) {  // both profile rows in one batch of loads
+        for (int k = tid2; k < 2 * nlay; k += nt) {  // both profile rows in one batch of loads
             const bool o3 = k >= nlay;
             const int kl = o3 ? k - nlay : k;
             if ((o3 ? 3 : 1) < d.ngas1) sh.vmr[(o3 ? 3 : 1) * nlay + kl] = (o3 ? as.vmr_o3 : as.vmr_h2o)[(size_t)nlay * col + kl];
@@ -537,7 +544,7 @@ __device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDim
         }
     }
     if (d.lw)
-        for (int k = tid; k < nlev; k += nt) {
+        for (int k = tid2; k < nlev; k += nt) {
             LevelRec<FT> lr;
             planck_pos(as.t_lev[(size_t)nlev * col + k], lk.t_planck, lk.n_t_plnk, lr.loc, lr.f);
             sh.lev[k] = lr;
