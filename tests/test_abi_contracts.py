@@ -85,3 +85,29 @@ def test_two_workspaces_from_two_host_threads(tables64):
             np.testing.assert_array_equal(results[i][0][0][n], serial[i][0][n])
         for n in SWN:
             np.testing.assert_array_equal(results[i][0][1][n], serial[i][1][n])
+
+
+def test_only_large_host_arrays_are_page_locked(tables32):
+    """hipHostRegister locks whole pages: only arrays of >= 32 MB (always mmapped: pages of their own) are registered;
+    smaller ones share heap pages with other objects and stay pageable (include/rrtmgp_hip.h; the rule that ended the
+    intermittent GPU memory faults of round 2).  Registrations go away with the workspace."""
+    t = tables32
+    nlay = 16
+    regs = lambda: _lib.allocation_counts()[2]  # noqa: E731
+    # 96 columns: nothing is large enough
+    as_, lb, sb = S.make_columns(96, nlay, np.float32, seed=1)
+    r0 = regs()
+    rte.solve_lw(rte.TwoStreamLWRTE(96, nlay, np.float32, lb), as_, t["lw"], t["cld_lw"])
+    small = regs() - r0
+    # 140 000 columns: layerdata (4, nlay, ncol) is 35.8 MB, every other array is below the floor
+    ncol = 140_000
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=1)
+    assert as_.layerdata.nbytes >= 32 << 20 > as_.t_lev.nbytes
+    slv = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
+    r1 = regs()
+    rte.solve_lw(slv, as_, t["lw"], t["cld_lw"])
+    big = regs() - r1
+    rte.solve_lw(slv, as_, t["lw"], t["cld_lw"])
+    again = regs() - r1 - big
+    # (the first small solve of a workspace page-locks its own bounce buffer: counted with the registrations)
+    assert small == 1 and big == 1 and again == 0, (small, big, again)
