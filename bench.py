@@ -16,7 +16,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys:
   * `roofline`: the dominant kernel's ALGORITHMIC HBM bytes against 8 TB/s as the task contract asks; the path
     is not HBM-bound (SURVEY.md F8), so the binding FP32-VALU figure is reported next to it as `valu`;
     `traffic` comes from the committed rocprofv3 PMC summary and carries the git SHA it was taken at
-    (`traffic_source`; null when the summary is missing);
+    (`traffic_source`; `traffic` is null when the summary is missing or was taken on other kernel sources — compared by a
+    hash of csrc/{common.h, device.h, solve_lw.hip, solve_sw.hip, Makefile});
   * `host_end_to_end`: the same workload handed over as HOST arrays (library stages H2D / D2H over PCIe
     every step): never `value`;
   * `precise_f32`: the IEEE-Float32 build of the library (-DRR_PRECISE_F32, correctly rounded div / sqrt);
@@ -279,7 +280,14 @@ def main():
             with open(prof) as fh:
                 pj = json.load(fh)
             k = pj.get("kernels", {}).get(dom)
-            if k and k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
+            # the counters belong to this line only if they were taken on the kernel sources that are being timed
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from rocprof_summary import kernel_source_sha256
+            same_sources = pj.get("kernel_source_sha256") == kernel_source_sha256(ROOT)
+            if not same_sources:
+                traffic_source = {"profile": pj.get("source"), "git_sha": pj.get("git_sha"),
+                                  "note": "profile was taken on other kernel sources: traffic withheld"}
+            elif k and k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
                 traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
                 traffic_source = {"profile": pj.get("source"), "git_sha": pj.get("git_sha"),
                                   "profiled_kernel_ms": k.get("avg_us", 0.0) / 1e3}

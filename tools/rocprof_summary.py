@@ -18,10 +18,23 @@ def q(dbp, sql):
         db.close()
 
 
+def kernel_source_sha256(repo):
+    """Hash of the sources the two column kernels are compiled from: bench.py only folds a profile's HBM counters into
+    its line when this matches the sources of the library it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("common.h", "device.h", "solve_lw.hip", "solve_sw.hip", "Makefile"):
+        with open(os.path.join(repo, "rrtmgp.jl_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def to_json(root, path, sha=None):
     """Per-kernel averages (duration in us, PMC counters per launch) as JSON for bench.py's `traffic`."""
     import json
-    out = {"source": os.path.basename(root.rstrip("/")), "git_sha": sha or None, "kernels": {}}
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {"source": os.path.basename(root.rstrip("/")), "git_sha": sha or None,
+           "kernel_source_sha256": kernel_source_sha256(repo), "kernels": {}}
     tr = os.path.join(root, "trace", "bench_results.db")
     if os.path.exists(tr):
         for name, calls, tot, avg, pct in q(tr, "select name, total_calls, total_duration, average, percentage from top_kernels"):
