@@ -338,14 +338,37 @@ int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_
 
 /* ---- state preparation (K9, K10) ----------------------------------------- */
 
-/* compute_col_gas!(device::CUDADevice, p_lev, col_dry, param_set, vmr_h2o, lat)  ext/cuda/optics.jl:2
- * p_lev (nlev, ncol) -> col_dry (nlay, ncol); vmr_h2o (nlay, ncol) or NULL; lat (ncol) or NULL. */
-int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry,
-                               const rrtmgp_params *params, const void *vmr_h2o, const void *lat);
+/* A 2-D array argument exactly as the reference hands it to these device methods: a dense `Array`, or one of the
+ * strided views the host code builds — `view(as.layerdata, i, :, :)` (src/optics/AtmosphericStates.jl:96-106: element
+ * stride 4), `view(vmr.vmr, idx_h2o, :, :)` (src/api/grid_adaptation.jl:204: element stride ngas), the getters' domain
+ * views `view(x, 1:n, :)` (src/api/getters.jl:42-43: column stride = rows of the parent).  Element (i, j) lives at
+ * ((FT *)ptr)[i * stride0 + j * stride1]; strides are in ELEMENTS and are what Julia's `strides(a)` returns.  A dense
+ * (n0, n1) array has stride0 = 1, stride1 = n0.  Both strides must be >= 1.  Nothing is copied on the caller's side:
+ * host views are staged as the memory span they cover (views of one parent array share one upload; a written view is
+ * staged in and out, so the parent's other elements come back unchanged), device views are used in place. */
+typedef struct rrtmgp_view2d {
+    void *ptr;
+    int64_t stride0; /* elements between (i, j) and (i + 1, j) */
+    int64_t stride1; /* elements between (i, j) and (i, j + 1) */
+} rrtmgp_view2d;
 
-/* compute_relative_humidity!(device::CUDADevice, rh, p_lay, t_lay, param_set, vmr_h2o)  ext/cuda/optics.jl:35 */
-int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
-                                         const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o);
+/* The three calls below take their extents explicitly and check them against the workspace: ncol <= the workspace's
+ * ncol (== for a multi-device workspace, whose shard ranges are fixed) and nlay <= its nlay — `heating_rate` passes the
+ * DOMAIN layer count, one less than the solver's when there is an isothermal boundary layer (src/api/standalone.jl:106-122). */
+
+/* compute_col_gas!(device::CUDADevice, p_lev, col_dry, param_set, vmr_h2o, lat)  ext/cuda/optics.jl:2
+ * (caller: update_concentrations!, src/api/grid_adaptation.jl:278-292, which passes getview_col_dry(as) and
+ * _vmr_h2o(as.vmr, idx_h2o)).  p_lev (nlay+1, ncol) -> col_dry (nlay, ncol); vmr_h2o (nlay, ncol) or NULL (a view whose
+ * `ptr` is NULL also means "absent": a binding can always pass a struct); lat FT (ncol), dense, or NULL. */
+int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay, const rrtmgp_view2d *p_lev,
+                               const rrtmgp_view2d *col_dry, const rrtmgp_params *params, const rrtmgp_view2d *vmr_h2o,
+                               const void *lat);
+
+/* compute_relative_humidity!(device::CUDADevice, rh, p_lay, t_lay, param_set, vmr_h2o)  ext/cuda/optics.jl:35
+ * (the reference's drivers pass rows 4, 2, 3 of layerdata: test/read_clear_sky.jl:162-169); all (nlay, ncol). */
+int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay,
+                                         const rrtmgp_view2d *rh, const rrtmgp_view2d *p_lay, const rrtmgp_view2d *t_lay,
+                                         const rrtmgp_params *params, const rrtmgp_view2d *vmr_h2o);
 
 /* prepare_atmosphere!(s::RRTMGPSolver)  src/api/update_fluxes.jl:252-281 — the whole
  * preparation cascade of src/api/grid_adaptation.jl, in place, one kernel, columns independent:
@@ -401,10 +424,11 @@ int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_s
 
 /* compute_gray_heating_rate!(device::CUDADevice, hr_lay, p_lev, ncol, nlay, flux_net, cp_d_, grav_)
  * ext/cuda/gray_atmosphere.jl:42-61 (body src/optics/GrayAtmosphere.jl:152-167; caller `heating_rate`,
- * src/api/standalone.jl:106-122):  hr_lay(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d
- * with flux_net, p_lev (nlev, ncol).  Dimensions are the workspace's. */
-int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev,
-                                         const void *flux_net, double cp_d, double grav);
+ * src/api/standalone.jl:106-122, which passes the domain views level_pressure(s) / net_flux(s)):
+ * hr_lay(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d with flux_net, p_lev (nlay+1, ncol). */
+int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay,
+                                         const rrtmgp_view2d *hr_lay, const rrtmgp_view2d *p_lev,
+                                         const rrtmgp_view2d *flux_net, double cp_d, double grav);
 
 /* ---- several GPUs from ONE host process (SURVEY.md §8(b) "Threading", §8(e)) ---------------
  *
@@ -428,13 +452,10 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void
  *    (ncol fastest) and the per-band fluxes (ncol in the middle) — are handed to the shards as
  *    strided blocks (inc_flux_ld, band_flux_ncol), and so are fluxes in the RRTMGP_LAYOUT_NCOL_NLEV
  *    layout (flux_ncol).
- *  - Host arrays of at least 32 MB are page-locked on first use (hipHostRegister; released by
- *    workspace_destroy, or when 8 solves of the workspace have not used them) so that the per-shard
- *    and per-chunk copies are true asynchronous DMA.  RRTMGP_HIP_HOST_REGISTER_MIN_BYTES changes
- *    the floor, RRTMGP_HIP_NO_HOST_REGISTER=1 turns registration off.  Smaller arrays are NOT
- *    registered: they live in the allocator's heap and share pages with unrelated objects, and a
- *    page lock that the runtime takes and drops on such a neighbour unmaps the shared page under
- *    a registration (GPU memory access fault).  From 32 MB on glibc always mmaps.
+ *  - Host arrays cross PCIe as true asynchronous DMA when they are page-locked: rrtmgp_hip_host_register below.
+ *  - Device arrays (all shards on the device that holds them): the call waits for work queued on that device before
+ *    the shards start (they run on private streams that nothing else orders behind the caller's producer stream) and
+ *    returns when every shard's kernels have finished.
  */
 int rrtmgp_hip_gas_lookup_create_multi(const rrtmgp_gas_lookup_desc *desc, const int32_t *device_ids, int ndev,
                                        rrtmgp_lookup **out);
@@ -446,6 +467,30 @@ int rrtmgp_hip_workspace_create_multi(const int32_t *device_ids, int ndev, int64
                                       rrtmgp_workspace **out);
 /* Number of shards of a workspace (1 for a single-device workspace). */
 int rrtmgp_hip_workspace_shards(const rrtmgp_workspace *ws);
+
+/* ---- page-locked host arrays: explicit lifetime ---------------------------------------------------
+ *
+ * With RRTMGP_MEM_HOST every solve copies state in and fluxes out.  Those copies are asynchronous DMA (and the pipelined
+ * host path overlaps them with the kernels) only from / to page-locked memory.  The OWNER of a host array registers it
+ * once, keeps it registered while it hands it to solves, and unregisters it before the memory is freed; a binding does
+ * that from the array's owner and finalizer (ext/RRTMGPHIPExt.jl `pin!`, rrtmgp.jl_amd/states.py `pin_host_array`).
+ *   - register is reference counted per exact (ptr, bytes) range; a range that overlaps a live registration of other
+ *     extents is refused (RRTMGP_EINVAL);
+ *   - any workspace, shard or pipeline chunk uses a registered range (or a sub-range of it) as it is; the library never
+ *     releases an explicit registration on its own, and unregister fails while a running solve is using the range;
+ *   - hipHostRegister locks whole pages: the array should own its pages.  glibc mmaps every allocation of at least 32 MB
+ *     (and most above 128 KB); smaller heap arrays share their first / last page with other objects, and a page lock the
+ *     HIP runtime takes and drops on such a neighbour for a pageable copy unmaps the shared page under the registration
+ *     (GPU memory access fault) — the bindings therefore register arrays of at least 32 MB only.
+ * Unregistered arrays work too (pageable copies).  RRTMGP_HIP_AUTO_HOST_REGISTER=1 makes the library itself register
+ * every unregistered host array of at least 32 MB (RRTMGP_HIP_HOST_REGISTER_MIN_BYTES) the first time a solve sees it and
+ * release it when other memory shows up on its pages or 64 registration passes did not touch it: a heuristic for callers
+ * that cannot manage lifetimes (an array freed and re-allocated at the same address with the same size cannot be told
+ * from the old one), hence opt-in. */
+int rrtmgp_hip_host_register(void *ptr, size_t bytes);
+int rrtmgp_hip_host_unregister(void *ptr);
+/* Live registrations (explicit and automatic), for tests. */
+int rrtmgp_hip_host_registered_count(void);
 
 /* ---- allocation accounting (zero-allocation contract, update_fluxes.jl:215-218) ------------ */
 
@@ -472,7 +517,7 @@ int rrtmgp_hip_last_error(char *buf, size_t n);
 const char *rrtmgp_hip_version(void);
 /* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,
  * 1 gas_lookup_desc, 2 cloud_lookup_desc, 3 aerosol_lookup_desc, 4 atmos_state, 5 lw_bcs,
- * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params); -1 otherwise.  Lets a
+ * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d); -1 otherwise.  Lets a
  * foreign-language binding verify its struct mirror at load time. */
 int rrtmgp_hip_abi_sizeof(int which);
 

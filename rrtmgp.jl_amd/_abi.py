@@ -94,6 +94,11 @@ class PrepareOpts(C.Structure):
                 ("face_z", vp), ("p_min", f64), ("t_min", f64), ("t_max", f64)]
 
 
+class View2D(C.Structure):
+    """rrtmgp_view2d: element (i, j) at ptr[i * stride0 + j * stride1], strides in elements (Julia's `strides`)."""
+    _fields_ = [("ptr", vp), ("stride0", i64), ("stride1", i64)]
+
+
 PREP_INTERPOLATE, PREP_ISOTHERMAL, PREP_CLIP, PREP_COL_DRY, PREP_ALL = 1, 2, 4, 8, 15
 PREP_REL_HUM = 16   # optional extra step: relative humidity refreshed in the same launch
 INTERP = {"none": 0, "arithmetic_mean": 1, "geometric_mean": 2, "uniform_z": 3, "uniform_p": 4, "best_fit": 5}

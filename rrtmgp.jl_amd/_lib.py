@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 _lib = None
 
 _P = C.c_void_p
+_V2 = C.POINTER(_abi.View2D)
 _SOLVE_SPECTRAL = [_P, _P, _P, _P, C.POINTER(_abi.AtmosState), _P, C.POINTER(_abi.FluxOut), C.POINTER(_abi.SolveOpts)]
 
 EXPORTS = {
@@ -44,9 +45,11 @@ EXPORTS = {
                                                        C.POINTER(_abi.SolveOpts)]),
     "rrtmgp_hip_rte_sw_noscat_solve_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), _P, C.POINTER(_abi.FluxOut),
                                                       C.POINTER(_abi.SolveOpts)]),
-    "rrtmgp_hip_compute_col_gas": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(_abi.Params), _P, _P]),
-    "rrtmgp_hip_compute_relative_humidity": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(_abi.Params), _P]),
-    "rrtmgp_hip_compute_gray_heating_rate": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_double, C.c_double]),
+    "rrtmgp_hip_compute_col_gas": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _V2, _V2, C.POINTER(_abi.Params), _V2, _P]),
+    "rrtmgp_hip_compute_relative_humidity": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _V2, _V2, _V2,
+                                                       C.POINTER(_abi.Params), _V2]),
+    "rrtmgp_hip_compute_gray_heating_rate": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, _V2, _V2, _V2, C.c_double,
+                                                       C.c_double]),
     "rrtmgp_hip_prepare_atmosphere": (C.c_int, [_P, C.POINTER(_abi.AtmosState), C.POINTER(_abi.Params),
                                                 C.POINTER(_abi.PrepareOpts)]),
     "rrtmgp_hip_prepare_atmosphere_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), C.POINTER(_abi.Params),
@@ -60,6 +63,9 @@ EXPORTS = {
     "rrtmgp_hip_workspace_create_multi": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                                     C.POINTER(_P)]),
     "rrtmgp_hip_workspace_shards": (C.c_int, [_P]),
+    "rrtmgp_hip_host_register": (C.c_int, [_P, C.c_size_t]),
+    "rrtmgp_hip_host_unregister": (C.c_int, [_P]),
+    "rrtmgp_hip_host_registered_count": (C.c_int, []),
     "rrtmgp_hip_allocation_counts": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
@@ -68,7 +74,8 @@ EXPORTS = {
 }
 
 ABI_STRUCTS = [_abi.MinorDesc, _abi.GasLookupDesc, _abi.CloudLookupDesc, _abi.AerosolLookupDesc, _abi.AtmosState,
-               _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params, _abi.PrepareOpts]
+               _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params, _abi.PrepareOpts,
+               _abi.View2D]
 
 
 class RRTMGPHipError(RuntimeError):

@@ -52,44 +52,51 @@ hipError_t rr_free(void *p) {
     return hipFree(p);
 }
 
-// Large host arrays handed over with RRTMGP_MEM_HOST are page-locked the first time they are seen, so that the
-// hipMemcpyAsync calls below are real asynchronous DMA (from pageable memory the runtime stages through its own
-// bounce buffers and the "asynchronous" copy blocks the host thread).  A host model keeps its state arrays for the
-// whole run, so this happens once per array: the registry is process-wide and keyed by address range.
+// ---- page-locked host arrays ---------------------------------------------------------------------------------------
+// hipMemcpyAsync is real asynchronous DMA only from / to page-locked memory (from pageable memory the runtime stages
+// through its own bounce buffers and the "asynchronous" copy blocks the host thread).  Page-locking has an EXPLICIT
+// lifetime: the owner of a host array registers it (rrtmgp_hip_host_register, include/rrtmgp_hip.h) and unregisters it
+// before the memory is freed; the bindings do that from the array's owner + finalizer (ext/RRTMGPHIPExt.jl `pin!`,
+// rrtmgp.jl_amd/states.py).  The registry is process-wide, keyed by address range, reference counted per exact range.
 //
-// Only arrays of at least 32 MB are registered (RRTMGP_HIP_HOST_REGISTER_MIN_BYTES; RRTMGP_HIP_NO_HOST_REGISTER=1 = never).
-// hipHostRegister locks whole PAGES.  A smaller array comes from the allocator's heap and shares its first and last page
-// with unrelated objects; when the runtime later locks and unlocks one of those for a pageable copy of its own, it
-// unmaps the shared page under our registration, and the next DMA through it dies with "Memory access fault by GPU"
-// (seen with 100 KB numpy arrays: 4 of 24 runs of the test suite).  From 32 MB on glibc always mmaps (its dynamic
-// threshold never exceeds that), so the pages belong to the array alone.
+// RRTMGP_HIP_AUTO_HOST_REGISTER=1 additionally registers, the first time a solve sees it, every host array of at least
+// 32 MB (RRTMGP_HIP_HOST_REGISTER_MIN_BYTES) that nobody registered.  That is a heuristic and therefore opt-in: a
+// registration that outlives its array keeps the OLD physical pages mapped for the GPU, and a new array that the allocator
+// places at the same address with the same size cannot be told from the old one (the copies would silently use the
+// old pages).  The floor is there because hipHostRegister locks whole PAGES: a smaller array comes from the allocator's
+// heap and shares its first and last page with unrelated objects; when the runtime later locks and unlocks one of those
+// for a pageable copy of its own, it unmaps the shared page under the registration and the next DMA through it dies with
+// "Memory access fault by GPU" (seen with 100 KB numpy arrays: 4 of 24 runs of the test suite).  From 32 MB on glibc always
+// mmaps, so the pages belong to the array alone.  Auto entries are released when a different array shows up on their
+// pages, or after 64 registration passes that did not touch them.
 //
-// A registration can outlive its array (the caller frees the array and keeps the workspace).  Rules that keep a stale
-// one from ever being used or found half-way by the HIP runtime:
-//   * a request counts as registered only on an EXACT (address, size) match, or inside a range that the solving
-//     workspace (or its multi-device head) verified in its current registration pass: the slabs of shards and chunks;
-//   * before any copy from / to host memory, every other registration that overlaps the buffer is released;
-//   * a workspace releases what none of its last 8 solves touched, and everything when it is destroyed.
+// Concurrency: a solve marks the entries it verified as in use (`users`) until its results are home; an entry with users
+// is never released by anybody (two workspaces on two threads may share the caller's state arrays), and a sub-range
+// request (the slab of a shard or of a pipeline chunk) counts as registered only inside an explicit entry or one this
+// workspace (or its multi-device head) is using.
 struct PinEntry {
     size_t bytes;
-    rrtmgp_workspace *owner;  // releases it (destroy, or 8 of its passes without a touch)
-    uint64_t last_used;       // the owner's pass counter at the last touch by the owner
-    // the workspace that matched it exactly most recently, and that workspace's pass: while that pass is current, its
-    // shards and chunks may use slabs INSIDE the range (two workspaces, e.g. LW and SW, share the caller's state arrays)
-    const rrtmgp_workspace *verified_by;
-    uint64_t verified_pass;
+    int refs;                 // explicit registrations of exactly this range (0: an auto entry)
+    uint64_t last_used;       // g_pin_pass at the last touch
+    std::vector<const rrtmgp_workspace *> users;  // solves in flight that verified it
+    bool used_by(const rrtmgp_workspace *ws) const {
+        return ws && std::find(users.begin(), users.end(), ws) != users.end();
+    }
 };
 static std::mutex g_pin_mu;
 static std::map<const char *, PinEntry> g_pins;
+static uint64_t g_pin_pass = 0;
 
 static void drop(std::map<const char *, PinEntry>::iterator &it) {
     (void)hipHostUnregister(const_cast<char *>(it->first));
     (void)hipGetLastError();
     it = g_pins.erase(it);
 }
-// Releases every registration that overlaps [p, p + bytes) and is not valid for it; returns true when a valid one covers
-// the whole buffer.  `touch`: mark it used in the owner's current pass.  (Caller holds g_pin_mu.)
-static bool settle(const rrtmgp_workspace *ws, const char *p, size_t bytes, bool touch) {
+static bool droppable(const PinEntry &e) { return e.refs == 0 && e.users.empty(); }
+// Looks at every registration that overlaps [p, p + bytes).  Returns true when a valid one covers the whole buffer;
+// auto entries that overlap it otherwise belong to memory that has been re-allocated since and are released (unless a
+// running solve is using them).  `use`: mark the covering entry as used by `ws`.  (Caller holds g_pin_mu.)
+static bool settle(const rrtmgp_workspace *ws, const char *p, size_t bytes, bool use) {
     bool covered = false;
     auto it = g_pins.upper_bound(p);
     if (it != g_pins.begin()) --it;
@@ -98,18 +105,16 @@ static bool settle(const rrtmgp_workspace *ws, const char *p, size_t bytes, bool
         if (b <= p) { ++it; continue; }
         PinEntry &e = it->second;
         const bool exact = a == p && e.bytes == bytes;
-        const bool mine = ws && e.verified_by && (e.verified_by == ws || e.verified_by == ws->head) &&
-                          e.verified_pass == e.verified_by->pin_pass;
-        if (exact || (a <= p && p + bytes <= b && mine)) {
+        const bool inside = a <= p && p + bytes <= b;
+        if (exact || (inside && (e.refs > 0 || e.used_by(ws) || (ws && e.used_by(ws->head))))) {
             covered = true;
-            if (touch && exact && ws) {
-                if (e.owner == ws) e.last_used = ws->pin_pass;
-                e.verified_by = ws;
-                e.verified_pass = ws->pin_pass;
-            }
+            e.last_used = g_pin_pass;
+            if (use && ws && !e.used_by(ws)) e.users.push_back(ws);
             ++it;
-        } else {
+        } else if (droppable(e)) {
             drop(it);
+        } else {
+            ++it;  // somebody else's live registration: left alone (the copy through it is then an ordinary pageable one)
         }
     }
     return covered;
@@ -119,47 +124,82 @@ void host_range_check(const rrtmgp_workspace *ws, const void *ptr, size_t bytes)
     std::lock_guard<std::mutex> lock(g_pin_mu);
     if (!g_pins.empty()) (void)settle(ws, (const char *)ptr, bytes, false);
 }
-static size_t host_register_min() {
-    static const size_t v = getenv("RRTMGP_HIP_NO_HOST_REGISTER") ? ~size_t(0)
+static size_t auto_register_min() {  // ~0: never (the default)
+    static const size_t v = !getenv("RRTMGP_HIP_AUTO_HOST_REGISTER") || getenv("RRTMGP_HIP_NO_HOST_REGISTER") ? ~size_t(0)
                             : getenv("RRTMGP_HIP_HOST_REGISTER_MIN_BYTES") ? (size_t)atoll(getenv("RRTMGP_HIP_HOST_REGISTER_MIN_BYTES"))
                                                                             : (size_t)32 << 20;
     return v;
 }
+// One of the caller's WHOLE host arrays, seen by the registration pass of a solve: true when it is page-locked.
 bool host_pin(rrtmgp_workspace *ws, const void *ptr, size_t bytes) {
     if (!ptr || !bytes) return false;
     const char *p = (const char *)ptr;
     std::lock_guard<std::mutex> lock(g_pin_mu);
     if (settle(ws, p, bytes, true)) return true;
-    if (bytes < host_register_min() || g_pins.size() >= 1024) return false;
+    if (bytes < auto_register_min() || g_pins.size() >= 1024) return false;
+    // nothing may be left under the new range (a live registration of other extents: stay pageable)
+    auto it = g_pins.upper_bound(p);
+    if (it != g_pins.begin()) --it;
+    for (; it != g_pins.end() && it->first < p + bytes; ++it)
+        if (it->first + it->second.bytes > p) return false;
     if (hipHostRegister(const_cast<char *>(p), bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     g_host_regs++;
-    g_pins.emplace(p, PinEntry{bytes, ws, ws->pin_pass, ws, ws->pin_pass});
+    g_pins.emplace(p, PinEntry{bytes, 0, g_pin_pass, {ws}});
     return true;
 }
-// A registration pass of `ws` (one per host-array solve) begins: what it touches from here on is current.
+// A registration pass of `ws` (one per host-array solve) begins ...
 void host_pin_begin(rrtmgp_workspace *ws) {
     std::lock_guard<std::mutex> lock(g_pin_mu);
-    ws->pin_pass++;
+    g_pin_pass++;
+    (void)ws;
 }
-// ... and ends: registrations of `ws` that none of its last 8 passes touched belong to arrays the caller no longer
-// hands over — probably freed — and are released.
-void host_pin_sweep(rrtmgp_workspace *ws) {
+// ... and the solve it belongs to has its results home: `ws` stops using what it verified, and auto entries that no
+// pass has touched for a while belong to arrays the caller no longer hands over — probably freed — and are released.
+void host_pin_end(rrtmgp_workspace *ws) {
     std::lock_guard<std::mutex> lock(g_pin_mu);
     for (auto it = g_pins.begin(); it != g_pins.end();) {
-        if (it->second.owner == ws && it->second.last_used + 8 < ws->pin_pass) drop(it);
+        auto &u = it->second.users;
+        u.erase(std::remove(u.begin(), u.end(), (const rrtmgp_workspace *)ws), u.end());
+        if (droppable(it->second) && it->second.last_used + 64 < g_pin_pass) drop(it);
         else ++it;
     }
 }
-void host_unpin_all(rrtmgp_workspace *ws) {
+int host_register_explicit(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return set_error(RRTMGP_EINVAL, "host_register: null pointer or zero size");
+    const char *p = (const char *)ptr;
     std::lock_guard<std::mutex> lock(g_pin_mu);
-    for (auto it = g_pins.begin(); it != g_pins.end();) {
-        if (it->second.verified_by == ws) it->second.verified_by = nullptr;
-        if (it->second.owner == ws) drop(it);
-        else ++it;
+    auto it = g_pins.upper_bound(p);
+    if (it != g_pins.begin()) --it;
+    while (it != g_pins.end() && it->first < p + bytes) {
+        if (it->first + it->second.bytes <= p) { ++it; continue; }
+        if (it->first == p && it->second.bytes == bytes) { it->second.refs++; return RRTMGP_OK; }  // (an auto entry becomes explicit)
+        if (!droppable(it->second)) return set_error(RRTMGP_EINVAL, "host_register: the range overlaps a live registration of other extents");
+        drop(it);
     }
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return set_error(RRTMGP_EHIP, std::string("hipHostRegister failed: ") + hipGetErrorString(e));
+    }
+    g_host_regs++;
+    g_pins.emplace(p, PinEntry{bytes, 1, g_pin_pass, {}});
+    return RRTMGP_OK;
+}
+int host_unregister_explicit(void *ptr) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    auto it = g_pins.find((const char *)ptr);
+    if (it == g_pins.end() || it->second.refs == 0) return set_error(RRTMGP_EINVAL, "host_unregister: not a registered range");
+    if (it->second.refs == 1 && !it->second.users.empty())
+        return set_error(RRTMGP_EINVAL, "host_unregister: a running solve is using the range");
+    if (--it->second.refs == 0) drop(it);
+    return RRTMGP_OK;
+}
+int host_registered_count() {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    return (int)g_pins.size();
 }
 
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
@@ -980,7 +1020,12 @@ static size_t host_pack_max() {
     return v;
 }
 
-// page-lock the caller's WHOLE host arrays (does something on the first call only); `ws` owns the registrations
+// The registration pass over the caller's WHOLE host arrays: which of them are page-locked (and, opt-in, locking the large
+// ones on first sight).  What it verifies stays marked as used by `ws` until the PinScope of the solve ends.
+struct PinScope {
+    rrtmgp_workspace *ws;
+    ~PinScope() { host_pin_end(ws); }
+};
 template <typename FT>
 static int pin_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
                   int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs, const rrtmgp_flux_out *flux,
@@ -990,7 +1035,6 @@ static int pin_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, con
     pin.pin_only = true;
     const int rc = solve_lw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
     if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
-    host_pin_sweep(ws);
     return rc;
 }
 template <typename FT>
@@ -1002,7 +1046,6 @@ static int pin_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, con
     pin.pin_only = true;
     const int rc = solve_sw_t<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &pin);
     if (need) *need = pin.need;  // host bytes the solve stages (what the packed small-solve path sizes its bounce buffer from)
-    host_pin_sweep(ws);
     return rc;
 }
 
@@ -1011,6 +1054,7 @@ static int solve_lw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_lw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     size_t need = 0;
+    PinScope scope{ws};
     TRY(pin_lw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &need));
     if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts)) {
         if (need && need <= host_pack_max()) {   // small solve: one bounce buffer, one DMA each way
@@ -1034,6 +1078,7 @@ static int solve_sw_host(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &
                          const DevAero<FT> *aero, int max_minor, const rrtmgp_atmos_state *as, const rrtmgp_sw_bcs *bcs,
                          const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts) {
     size_t need = 0;
+    PinScope scope{ws};
     TRY(pin_sw<FT>(ws, twostream, lk, cld, aero, max_minor, as, bcs, flux, opts, &need));
     if (!bcs || !host_pipeline_applies(as, bcs->mem, flux, opts)) {
         if (need && need <= host_pack_max()) {
@@ -1161,47 +1206,83 @@ static int solve_gray_sw_t(rrtmgp_workspace *ws, int twostream, const rrtmgp_gra
     return st.finish();
 }
 
+// ---- 2-D view arguments (rrtmgp_view2d) of compute_col_gas! / compute_relative_humidity! / compute_gray_heating_rate! ----
+// The reference passes strided views (rows of layerdata, a row of Vmr.vmr, domain views of level arrays).  Device views
+// are used in place.  A host view is staged as the memory span it covers; views whose spans overlap (rows of ONE parent
+// array) share one staging buffer and one upload; a span that is written is staged in AND out unless the written view is
+// dense and alone in it, so whatever else lives in the span comes back as it went in.
+struct ViewArg {
+    const rrtmgp_view2d *v;
+    size_t n0, n1;
+    bool out;
+    char *dev = nullptr;  // device address of element (0, 0)
+    const char *lo() const { return (const char *)v->ptr; }
+    size_t span(size_t E) const { return ((n0 - 1) * (size_t)v->stride0 + (n1 - 1) * (size_t)v->stride1 + 1) * E; }
+    bool dense() const { return v->stride0 == 1 && (size_t)v->stride1 == n0; }
+};
+static int stage_views(Stager &st, int mem, ViewArg *a, int n, size_t E) {
+    static const int slots[4] = {S_PLEV, S_PLAY, S_TLAY, S_AUX0};
+    for (int i = 0; i < n; i++) {
+        if (!a[i].v) continue;
+        RR_CHECK(a[i].v->ptr && a[i].v->stride0 >= 1 && a[i].v->stride1 >= 1, "view2d: null pointer or non-positive stride");
+        if (mem == RRTMGP_MEM_DEVICE) a[i].dev = (char *)a[i].v->ptr;
+    }
+    if (mem == RRTMGP_MEM_DEVICE) return RRTMGP_OK;
+    RR_CHECK(n <= 4, "internal: too many view arguments");
+    int order[4], m = 0;
+    for (int i = 0; i < n; i++) if (a[i].v) order[m++] = i;
+    std::sort(order, order + m, [&](int x, int y) { return a[x].lo() < a[y].lo(); });
+    for (int i = 0, g = 0; i < m; g++) {
+        const char *lo = a[order[i]].lo(), *hi = lo + a[order[i]].span(E);
+        int j = i + 1;
+        while (j < m && a[order[j]].lo() < hi) { hi = std::max(hi, a[order[j]].lo() + a[order[j]].span(E)); j++; }
+        bool any_out = false;
+        for (int t = i; t < j; t++) any_out = any_out || a[order[t]].out;
+        void *dev = nullptr;
+        if (!any_out) TRY(st.in(mem, slots[g], lo, (size_t)(hi - lo), (const void **)&dev));
+        else if (j == i + 1 && a[order[i]].dense()) TRY(st.out(mem, slots[g], const_cast<char *>(lo), (size_t)(hi - lo), &dev));
+        else TRY(st.inout(mem, slots[g], lo, (size_t)(hi - lo), &dev));
+        for (int t = i; t < j; t++) a[order[t]].dev = (char *)dev + (a[order[t]].lo() - lo);
+        i = j;
+    }
+    return RRTMGP_OK;
+}
+template <typename T>
+static View2<T> dev_view(const ViewArg &a) {
+    return a.v ? View2<T>{(T *)a.dev, a.v->stride0, a.v->stride1} : View2<T>{nullptr, 0, 0};
+}
+
 template <typename FT>
-static int col_gas_t(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry, const rrtmgp_params *ps,
-                     const void *vmr_h2o, const void *lat) {
-    const size_t E = sizeof(FT), ncol = ws->ncol, nlay = ws->nlay;
+static int col_gas_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *p_lev,
+                     const rrtmgp_view2d *col_dry, const rrtmgp_params *ps, const rrtmgp_view2d *vmr_h2o, const void *lat) {
     Stager st{ws, {}};
-    const FT *pl, *h2o, *la;
-    FT *cd;
-    TRY(st.in(mem, S_PLEV, p_lev, (nlay + 1) * ncol * E, (const void **)&pl));
-    TRY(st.in(mem, S_VMR_H2O, vmr_h2o, nlay * ncol * E, (const void **)&h2o));
-    TRY(st.in(mem, S_LAT, lat, ncol * E, (const void **)&la));
-    TRY(st.out(mem, S_AUX0, col_dry, nlay * ncol * E, (void **)&cd));
-    TRY(launch_col_gas<FT>(ws, (int)ncol, (int)nlay, pl, cd, *ps, h2o, la));
+    ViewArg a[3] = {{p_lev, nlay + 1, ncol, false}, {col_dry, nlay, ncol, true}, {vmr_h2o, nlay, ncol, false}};
+    TRY(stage_views(st, mem, a, 3, sizeof(FT)));
+    const FT *la;
+    TRY(st.in(mem, S_LAT, lat, ncol * sizeof(FT), (const void **)&la));
+    TRY(launch_col_gas<FT>(ws, (int)ncol, (int)nlay, dev_view<const FT>(a[0]), dev_view<FT>(a[1]), *ps, dev_view<const FT>(a[2]), la));
     return st.finish();
 }
 
 template <typename FT>
-static int rel_hum_t(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay, const void *t_lay,
-                     const rrtmgp_params *ps, const void *vmr_h2o) {
-    const size_t n = (size_t)ws->ncol * ws->nlay * sizeof(FT);
+static int rel_hum_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *rh,
+                     const rrtmgp_view2d *p_lay, const rrtmgp_view2d *t_lay, const rrtmgp_params *ps, const rrtmgp_view2d *vmr_h2o) {
     Stager st{ws, {}};
-    const FT *pl, *tl, *h2o;
-    FT *r;
-    TRY(st.in(mem, S_PLAY, p_lay, n, (const void **)&pl));
-    TRY(st.in(mem, S_TLAY, t_lay, n, (const void **)&tl));
-    TRY(st.in(mem, S_VMR_H2O, vmr_h2o, n, (const void **)&h2o));
-    TRY(st.out(mem, S_AUX0, rh, n, (void **)&r));
-    TRY(launch_rel_hum<FT>(ws, (int)ws->ncol, (int)ws->nlay, r, pl, tl, *ps, h2o));
+    ViewArg a[4] = {{rh, nlay, ncol, true}, {p_lay, nlay, ncol, false}, {t_lay, nlay, ncol, false}, {vmr_h2o, nlay, ncol, false}};
+    TRY(stage_views(st, mem, a, 4, sizeof(FT)));
+    TRY(launch_rel_hum<FT>(ws, (int)ncol, (int)nlay, dev_view<FT>(a[0]), dev_view<const FT>(a[1]), dev_view<const FT>(a[2]), *ps,
+                           dev_view<const FT>(a[3])));
     return st.finish();
 }
 
 template <typename FT>
-static int heating_rate_t(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev, const void *flux_net, double cp_d,
-                          double grav) {
-    const size_t E = sizeof(FT), ncol = ws->ncol, nlay = ws->nlay;
+static int heating_rate_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *hr_lay,
+                          const rrtmgp_view2d *p_lev, const rrtmgp_view2d *flux_net, double cp_d, double grav) {
     Stager st{ws, {}};
-    const FT *pl, *fn;
-    FT *hr;
-    TRY(st.in(mem, S_PLEV, p_lev, (nlay + 1) * ncol * E, (const void **)&pl));
-    TRY(st.in(mem, S_FLUX_NET, flux_net, (nlay + 1) * ncol * E, (const void **)&fn));
-    TRY(st.out(mem, S_AUX0, hr_lay, nlay * ncol * E, (void **)&hr));
-    TRY(launch_heating_rate<FT>(ws, (int)ncol, (int)nlay, hr, fn, pl, grav, cp_d));
+    ViewArg a[3] = {{hr_lay, nlay, ncol, true}, {p_lev, nlay + 1, ncol, false}, {flux_net, nlay + 1, ncol, false}};
+    TRY(stage_views(st, mem, a, 3, sizeof(FT)));
+    TRY(launch_heating_rate<FT>(ws, (int)ncol, (int)nlay, dev_view<FT>(a[0]), dev_view<const FT>(a[2]), dev_view<const FT>(a[1]),
+                                grav, cp_d));
     return st.finish();
 }
 
@@ -1289,8 +1370,9 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
     if (!ws) return RRTMGP_OK;
     (void)hipSetDevice(ws->device);
     (void)hipStreamSynchronize(ws->stream);
-    host_unpin_all(ws);
-    if (!ws->shards.empty()) {  // a multi-device head owns its shards and nothing else
+    host_pin_end(ws);
+    if (!ws->shards.empty()) {  // a multi-device head owns its shards (and their worker threads) and nothing else
+        shard_workers_destroy(ws->workers);
         for (rrtmgp_workspace *s : ws->shards) rrtmgp_hip_workspace_destroy(s);
         delete ws;
         return RRTMGP_OK;
@@ -1379,7 +1461,8 @@ static int multi_spectral(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, const 
         if (!g || (cld && !c) || (aero && !ae))
             return set_error(RRTMGP_EINVAL, "a lookup has no replica on one of the workspace's devices (use *_lookup_create_multi)");
         return call(sw, g, c, ae, &a, &b, &f, &o);
-    });
+    }, as->mem == RRTMGP_MEM_DEVICE || bcs->mem == RRTMGP_MEM_DEVICE || flux->mem == RRTMGP_MEM_DEVICE ||
+       (opts && opts->metric_scaling && opts->metric_mem == RRTMGP_MEM_DEVICE));
 }
 static int check_multi_spectral(rrtmgp_workspace *ws, const rrtmgp_lookup *gas, const rrtmgp_atmos_state *as, const void *bcs,
                                 int bcs_mem, const rrtmgp_flux_out *flux, const rrtmgp_solve_opts *opts, const void *inc_flux) {
@@ -1402,6 +1485,7 @@ int rrtmgp_hip_rte_lw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *l
         TRY(check_multi_spectral(ws, lookup_lw, as, bcs, bcs ? bcs->mem : 0, flux, opts, bcs ? bcs->inc_flux : nullptr));
         const rrtmgp_lookup *g = head_replica(ws, lookup_lw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
         RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        PinScope scope{ws};
         TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
         return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
@@ -1420,6 +1504,7 @@ int rrtmgp_hip_rte_lw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
         TRY(check_multi_spectral(ws, lookup_lw, as, bcs, bcs ? bcs->mem : 0, flux, opts, bcs ? bcs->inc_flux : nullptr));
         const rrtmgp_lookup *g = head_replica(ws, lookup_lw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
         RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        PinScope scope{ws};
         TRY(GAS_DISPATCH(ws, pin_lw, g, c, ae, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_lw);
         return multi_spectral(ws, lookup_lw, cld, aero, as, bcs, flux, opts,
@@ -1438,6 +1523,7 @@ int rrtmgp_hip_rte_sw_2stream_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *l
         TRY(check_multi_spectral(ws, lookup_sw, as, bcs, bcs ? bcs->mem : 0, flux, opts, nullptr));
         const rrtmgp_lookup *g = head_replica(ws, lookup_sw), *c = head_replica(ws, cld), *ae = head_replica(ws, aero);
         RR_CHECK(g && (!cld || c) && (!aero || ae), "a lookup has no replica on the workspace's first device");
+        PinScope scope{ws};
         TRY(GAS_DISPATCH(ws, pin_sw, g, c, ae, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_sw);
         return multi_spectral(ws, lookup_sw, cld, aero, as, bcs, flux, opts,
@@ -1456,6 +1542,7 @@ int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
         TRY(check_multi_spectral(ws, lookup_sw, as, bcs, bcs ? bcs->mem : 0, flux, opts, nullptr));
         const rrtmgp_lookup *g = head_replica(ws, lookup_sw);
         RR_CHECK(g, "the lookup has no replica on the workspace's first device");
+        PinScope scope{ws};
         TRY(GAS_DISPATCH(ws, pin_sw, g, cld, aero, as, bcs, flux, opts));
         const size_t nb = (size_t)n_bnd_of(ws, lookup_sw);
         return multi_spectral(ws, lookup_sw, cld, aero, as, bcs, flux, opts,
@@ -1489,7 +1576,8 @@ static int multi_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const B
         slice_flux(f, o, sl, nlev, (size_t)gs->ncol);
         slice_bcs(b, sl);
         return call(sw, &g, &b, &f, &o);
-    });
+    }, gs->mem == RRTMGP_MEM_DEVICE || bcs->mem == RRTMGP_MEM_DEVICE || flux->mem == RRTMGP_MEM_DEVICE ||
+       (opts && opts->metric_scaling && opts->metric_mem == RRTMGP_MEM_DEVICE));
 }
 static void slice_gray_lw_bcs(rrtmgp_lw_bcs &b, const ColumnSlice &sl) { b.sfc_emis = sl.adv(b.sfc_emis, 1); b.inc_flux = sl.adv(b.inc_flux, 1); }
 static void slice_gray_sw_bcs(rrtmgp_sw_bcs &b, const ColumnSlice &sl) { slice_sw_bcs(b, sl, 1); }
@@ -1540,53 +1628,78 @@ int rrtmgp_hip_rte_sw_noscat_solve_gray(rrtmgp_workspace *ws, const rrtmgp_gray_
                                    : solve_gray_sw_t<double>(ws, 0, as, bcs, flux, opts);
 }
 
-int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, const void *p_lev, void *col_dry,
-                               const rrtmgp_params *params, const void *vmr_h2o, const void *lat) {
+// extents of the three view-based calls against the workspace; a view of a multi-device workspace advanced to a shard's
+// first column keeps its strides
+static int check_view_extents(const rrtmgp_workspace *ws, int64_t ncol, int64_t nlay) {
+    RR_CHECK(ncol >= 1 && nlay >= 1, "ncol and nlay must be positive");
+    RR_CHECK(nlay <= ws->nlay, "nlay exceeds the workspace's");
+    if (!ws->shards.empty() || ws->head) RR_CHECK(ncol == ws->ncol, "ncol differs from the (multi-device) workspace's");
+    else RR_CHECK(ncol <= ws->ncol, "ncol exceeds the workspace's");
+    return RRTMGP_OK;
+}
+static rrtmgp_view2d col_adv(const rrtmgp_view2d *v, size_t E, size_t c0) {
+    rrtmgp_view2d r = *v;
+    r.ptr = (char *)v->ptr + (size_t)v->stride1 * c0 * E;
+    return r;
+}
+
+int rrtmgp_hip_compute_col_gas(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay, const rrtmgp_view2d *p_lev,
+                               const rrtmgp_view2d *col_dry, const rrtmgp_params *params, const rrtmgp_view2d *vmr_h2o,
+                               const void *lat) {
     RR_CHECK(ws && p_lev && col_dry && params, "null argument");
+    if (vmr_h2o && !vmr_h2o->ptr) vmr_h2o = nullptr;  // an absent optional array may also be a view with a null pointer
+    TRY(check_view_extents(ws, ncol, nlay));
     if (!ws->shards.empty()) {
-        const size_t nlay = (size_t)ws->nlay;
-        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
-            const ColumnSlice sl{(size_t)ws->ftype, c0};
-            return rrtmgp_hip_compute_col_gas(sw, mem, sl.adv(p_lev, nlay + 1), sl.adv(col_dry, nlay), params,
-                                              sl.adv(vmr_h2o, nlay), sl.adv(lat, 1));
-        });
+        RR_CHECK(p_lev->ptr && col_dry->ptr, "view2d: null pointer");
+        const size_t E = (size_t)ws->ftype;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const ColumnSlice sl{E, c0};
+            const rrtmgp_view2d pl = col_adv(p_lev, E, c0), cd = col_adv(col_dry, E, c0);
+            rrtmgp_view2d h{};
+            if (vmr_h2o) h = col_adv(vmr_h2o, E, c0);
+            return rrtmgp_hip_compute_col_gas(sw, mem, (int64_t)nc, nlay, &pl, &cd, params, vmr_h2o ? &h : nullptr, sl.adv(lat, 1));
+        }, mem == RRTMGP_MEM_DEVICE);
     }
     RR_HIP(hipSetDevice(ws->device));
-    return ws->ftype == RRTMGP_F32 ? col_gas_t<float>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat)
-                                   : col_gas_t<double>(ws, mem, p_lev, col_dry, params, vmr_h2o, lat);
+    return ws->ftype == RRTMGP_F32 ? col_gas_t<float>(ws, mem, (size_t)ncol, (size_t)nlay, p_lev, col_dry, params, vmr_h2o, lat)
+                                   : col_gas_t<double>(ws, mem, (size_t)ncol, (size_t)nlay, p_lev, col_dry, params, vmr_h2o, lat);
 }
 
-int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, void *rh, const void *p_lay,
-                                         const void *t_lay, const rrtmgp_params *params, const void *vmr_h2o) {
+int rrtmgp_hip_compute_relative_humidity(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay,
+                                         const rrtmgp_view2d *rh, const rrtmgp_view2d *p_lay, const rrtmgp_view2d *t_lay,
+                                         const rrtmgp_params *params, const rrtmgp_view2d *vmr_h2o) {
     RR_CHECK(ws && rh && p_lay && t_lay && params && vmr_h2o, "null argument");
+    TRY(check_view_extents(ws, ncol, nlay));
     if (!ws->shards.empty()) {
-        const size_t nlay = (size_t)ws->nlay;
-        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
-            const ColumnSlice sl{(size_t)ws->ftype, c0};
-            return rrtmgp_hip_compute_relative_humidity(sw, mem, sl.adv(rh, nlay), sl.adv(p_lay, nlay), sl.adv(t_lay, nlay),
-                                                        params, sl.adv(vmr_h2o, nlay));
-        });
+        RR_CHECK(rh->ptr && p_lay->ptr && t_lay->ptr && vmr_h2o->ptr, "view2d: null pointer");
+        const size_t E = (size_t)ws->ftype;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const rrtmgp_view2d r = col_adv(rh, E, c0), p = col_adv(p_lay, E, c0), t = col_adv(t_lay, E, c0), h = col_adv(vmr_h2o, E, c0);
+            return rrtmgp_hip_compute_relative_humidity(sw, mem, (int64_t)nc, nlay, &r, &p, &t, params, &h);
+        }, mem == RRTMGP_MEM_DEVICE);
     }
     RR_HIP(hipSetDevice(ws->device));
-    return ws->ftype == RRTMGP_F32 ? rel_hum_t<float>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o)
-                                   : rel_hum_t<double>(ws, mem, rh, p_lay, t_lay, params, vmr_h2o);
+    return ws->ftype == RRTMGP_F32 ? rel_hum_t<float>(ws, mem, (size_t)ncol, (size_t)nlay, rh, p_lay, t_lay, params, vmr_h2o)
+                                   : rel_hum_t<double>(ws, mem, (size_t)ncol, (size_t)nlay, rh, p_lay, t_lay, params, vmr_h2o);
 }
 
-int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, void *hr_lay, const void *p_lev,
-                                         const void *flux_net, double cp_d, double grav) {
+int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, int64_t ncol, int64_t nlay,
+                                         const rrtmgp_view2d *hr_lay, const rrtmgp_view2d *p_lev,
+                                         const rrtmgp_view2d *flux_net, double cp_d, double grav) {
     RR_CHECK(ws && hr_lay && p_lev && flux_net, "null argument");
     RR_CHECK(cp_d != 0.0, "cp_d must not be zero");
+    TRY(check_view_extents(ws, ncol, nlay));
     if (!ws->shards.empty()) {
-        const size_t nlay = (size_t)ws->nlay;
-        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t) -> int {
-            const ColumnSlice sl{(size_t)ws->ftype, c0};
-            return rrtmgp_hip_compute_gray_heating_rate(sw, mem, sl.adv(hr_lay, nlay), sl.adv(p_lev, nlay + 1),
-                                                        sl.adv(flux_net, nlay + 1), cp_d, grav);
-        });
+        RR_CHECK(hr_lay->ptr && p_lev->ptr && flux_net->ptr, "view2d: null pointer");
+        const size_t E = (size_t)ws->ftype;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const rrtmgp_view2d h = col_adv(hr_lay, E, c0), p = col_adv(p_lev, E, c0), f = col_adv(flux_net, E, c0);
+            return rrtmgp_hip_compute_gray_heating_rate(sw, mem, (int64_t)nc, nlay, &h, &p, &f, cp_d, grav);
+        }, mem == RRTMGP_MEM_DEVICE);
     }
     RR_HIP(hipSetDevice(ws->device));
-    return ws->ftype == RRTMGP_F32 ? heating_rate_t<float>(ws, mem, hr_lay, p_lev, flux_net, cp_d, grav)
-                                   : heating_rate_t<double>(ws, mem, hr_lay, p_lev, flux_net, cp_d, grav);
+    return ws->ftype == RRTMGP_F32 ? heating_rate_t<float>(ws, mem, (size_t)ncol, (size_t)nlay, hr_lay, p_lev, flux_net, cp_d, grav)
+                                   : heating_rate_t<double>(ws, mem, (size_t)ncol, (size_t)nlay, hr_lay, p_lev, flux_net, cp_d, grav);
 }
 
 int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_params *params,
@@ -1603,7 +1716,7 @@ int rrtmgp_hip_prepare_atmosphere(rrtmgp_workspace *ws, const rrtmgp_atmos_state
             slice_state(a, sl, nc);
             o.center_z = sl.adv(o.center_z, nlay); o.face_z = sl.adv(o.face_z, nlay + 1);
             return rrtmgp_hip_prepare_atmosphere(sw, &a, params, &o);
-        });
+        }, as->mem == RRTMGP_MEM_DEVICE);
     }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? prepare_t<float>(ws, as, params, opts) : prepare_t<double>(ws, as, params, opts);
@@ -1623,12 +1736,16 @@ int rrtmgp_hip_prepare_atmosphere_gray(rrtmgp_workspace *ws, const rrtmgp_gray_s
             slice_gray(g, sl, nc);
             o.center_z = sl.adv(o.center_z, nlay); o.face_z = sl.adv(o.face_z, nlay + 1);
             return rrtmgp_hip_prepare_atmosphere_gray(sw, &g, params, &o);
-        });
+        }, as->mem == RRTMGP_MEM_DEVICE);
     }
     RR_HIP(hipSetDevice(ws->device));
     return ws->ftype == RRTMGP_F32 ? prepare_gray_t<float>(ws, as, params, opts)
                                    : prepare_gray_t<double>(ws, as, params, opts);
 }
+
+int rrtmgp_hip_host_register(void *ptr, size_t bytes) { return host_register_explicit(ptr, bytes); }
+int rrtmgp_hip_host_unregister(void *ptr) { return host_unregister_explicit(ptr); }
+int rrtmgp_hip_host_registered_count(void) { return host_registered_count(); }
 
 int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, int64_t *host_registrations) {
     if (device_allocs) *device_allocs = g_dev_allocs.load();
@@ -1664,6 +1781,7 @@ int rrtmgp_hip_abi_sizeof(int which) {
         case 9: return (int)sizeof(rrtmgp_gray_state);
         case 10: return (int)sizeof(rrtmgp_params);
         case 11: return (int)sizeof(rrtmgp_prepare_opts);
+        case 12: return (int)sizeof(rrtmgp_view2d);
         default: return -1;
     }
 }

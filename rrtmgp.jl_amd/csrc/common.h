@@ -112,6 +112,8 @@ constexpr int MINOR_GROUP = 4;  // minor-gas contributors fetched by one load pe
 
 }  // namespace rrtmgp
 
+namespace rrtmgp { struct ShardWorkers; void shard_workers_destroy(ShardWorkers *); }
+
 struct rrtmgp_lookup {
     int kind;
     int ftype;
@@ -140,7 +142,6 @@ struct rrtmgp_workspace {
     bool timed = false;
     int n_cu = 0;
     rrtmgp_workspace *head = nullptr;  // shard of a multi-device workspace: its head
-    uint64_t pin_pass = 0;  // registration passes so far (host-array solves): ages this workspace's page-lock registrations
     // staging mirrors for host-memory callers, keyed by slot; the second set and the copy stream serve the
     // pipelined host path (column chunks: chunk c+1 is uploaded while chunk c is being solved)
     std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
@@ -158,6 +159,7 @@ struct rrtmgp_workspace {
     // resources of its own); shard s covers the global columns [shard_c0[s], shard_c0[s + 1])
     std::vector<rrtmgp_workspace *> shards;
     std::vector<int64_t> shard_c0;
+    rrtmgp::ShardWorkers *workers = nullptr;  // persistent host threads of the shards (multi.hip), created by the first call
 };
 
 namespace rrtmgp {
@@ -183,12 +185,12 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes);
 // every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
 hipError_t rr_malloc(void **p, size_t bytes);
 hipError_t rr_free(void *p);
-// page-lock a caller's host array once (process-wide registry, owner = ws); false = it stays pageable
+// page-locked host arrays (process-wide registry, api.hip): is this whole caller array registered (explicitly, or —
+// opt-in — by the library on first sight)?  `ws` uses it until host_pin_end(ws)
 bool host_pin(rrtmgp_workspace *ws, const void *p, size_t bytes);
 void host_pin_begin(rrtmgp_workspace *ws);
-void host_pin_sweep(rrtmgp_workspace *ws);
-void host_range_check(const rrtmgp_workspace *ws, const void *p, size_t bytes);  // drops registrations that overlap [p, p + bytes) without containing it
-void host_unpin_all(rrtmgp_workspace *ws);
+void host_pin_end(rrtmgp_workspace *ws);
+void host_range_check(const rrtmgp_workspace *ws, const void *p, size_t bytes);  // releases stale registrations under [p, p + bytes)
 
 // the replica of `lk` that lives on `device` (lk itself when it does), or nullptr
 const rrtmgp_lookup *lookup_on(const rrtmgp_lookup *lk, int device);
@@ -196,7 +198,10 @@ const std::string &last_error_string();
 
 // Runs `shard_call(shard_workspace, first_column, n_columns)` for every shard of a multi-device workspace,
 // concurrently (one host thread per shard), and returns the first failure (message preserved).
-int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, size_t, size_t)> &shard_call);
+// `device_arrays`: the caller's arrays live in device memory (all shards on that device): work queued on the device is
+// waited for first, and the call returns when every shard's stream has drained.
+int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, size_t, size_t)> &shard_call,
+              bool device_arrays = false);
 
 // Launchers implemented in the .hip translation units.  `which`: 1 = two-stream, 0 = no-scattering.
 template <typename FT>
@@ -221,16 +226,23 @@ template <typename FT>
 int launch_gray_sw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, const GrayArgs &ga, const FT *p_lay,
                    const FT *p_lev, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
                    const DevFlux<FT> &fl);
+// a 2-D array argument as the reference passes it (rrtmgp_view2d): element (i, j) at p[i * s0 + j * s1]
+template <typename T>
+struct View2 {
+    T *p;
+    int64_t s0, s1;
+    __host__ __device__ __forceinline__ T &operator()(int i, int j) const { return p[(int64_t)i * s0 + (int64_t)j * s1]; }
+};
 template <typename FT>
-int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, const FT *p_lev, FT *col_dry, const rrtmgp_params &ps,
-                   const FT *vmr_h2o, const FT *lat);
+int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, View2<const FT> p_lev, View2<FT> col_dry, const rrtmgp_params &ps,
+                   View2<const FT> vmr_h2o, const FT *lat);
 template <typename FT>
-int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p_lay, const FT *t_lay,
-                   const rrtmgp_params &ps, const FT *vmr_h2o);
+int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, View2<FT> rh, View2<const FT> p_lay, View2<const FT> t_lay,
+                   const rrtmgp_params &ps, View2<const FT> vmr_h2o);
 
 template <typename FT>
-int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, double grav,
-                        double cp_d);
+int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, View2<FT> hr_lay, View2<const FT> flux_net,
+                        View2<const FT> p_lev, double grav, double cp_d);
 
 // prepare_atmosphere!: the state through layer / level accessors, so that AtmosphericState
 // (layerdata rows, element stride 4) and GrayAtmosphericState (separate arrays) share one kernel.

@@ -248,43 +248,48 @@ __global__ void gray_sw_kernel(int ncol, int nlay, GrayArgs ga, const FT *p_lay,
     }
 }
 
-// compute_col_gas_kernel!, src/optics/gas_optics.jl:16-47
+// compute_col_gas_kernel!, src/optics/gas_optics.jl:16-47.  The arrays arrive as the reference passes them: dense or
+// strided 2-D views (View2<FT>: element (k, col) at p[k * s0 + col * s1]).
 template <typename FT>
-__global__ void col_gas_kernel(int ncol, int nlay, const FT *p_lev, FT *col_dry, FT mol_m_dry, FT mol_m_h2o, FT avogadro,
-                               FT helmert1, const FT *vmr_h2o, const FT *lat) {
+__global__ void col_gas_kernel(int ncol, int nlay, View2<const FT> p_lev, View2<FT> col_dry, FT mol_m_dry, FT mol_m_h2o,
+                               FT avogadro, FT helmert1, View2<const FT> vmr_h2o, const FT *lat) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)ncol * nlay) return;
     const int col = (int)(i / nlay), k = (int)(i - (size_t)col * nlay);
     const FT g0 = lat ? helmert1 - FT(0.02586) * m_cos(FT(2) * Num<FT>::pi() * lat[col] / FT(180)) : helmert1;
-    const FT dp = p_lev[(size_t)(nlay + 1) * col + k] - p_lev[(size_t)(nlay + 1) * col + k + 1];
-    const FT h2o = vmr_h2o ? vmr_h2o[i] : FT(0);
+    const FT dp = p_lev(k, col) - p_lev(k + 1, col);
+    const FT h2o = vmr_h2o.p ? vmr_h2o(k, col) : FT(0);
     const FT m_air = (mol_m_dry + mol_m_h2o * h2o);
-    col_dry[i] = (dp * avogadro / (FT(100 * 100) * m_air * g0));
+    col_dry(k, col) = (dp * avogadro / (FT(100 * 100) * m_air * g0));
 }
 
 // compute_relative_humidity_kernel!, src/optics/gas_optics.jl:58-80
 template <typename FT>
-__global__ void rel_hum_kernel(size_t n, FT *rh, const FT *p_lay, const FT *t_lay, FT mwd, const FT *vmr_h2o) {
+__global__ void rel_hum_kernel(int ncol, int nlay, View2<FT> rh, View2<const FT> p_lay, View2<const FT> t_lay, FT mwd,
+                               View2<const FT> vmr_h2o) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const FT mmr = vmr_h2o[i] * mwd;
+    if (i >= (size_t)ncol * nlay) return;
+    const int col = (int)(i / nlay), k = (int)(i - (size_t)col * nlay);
+    const FT mmr = vmr_h2o(k, col) * mwd;
     const FT q = mmr / (FT(1) + mmr);
     const FT q_tmp = m_max(FT(1e-7), q);
-    const FT es = m_exp((FT(17.67) * (t_lay[i] - FT(273.16))) / (t_lay[i] - FT(29.65)));
-    rh[i] = m_max(FT(0.01) * (FT(0.263) * p_lay[i] * q_tmp) / es, FT(0));
+    const FT t = t_lay(k, col);
+    const FT es = m_exp((FT(17.67) * (t - FT(273.16))) / (t - FT(29.65)));
+    rh(k, col) = m_max(FT(0.01) * (FT(0.263) * p_lay(k, col) * q_tmp) / es, FT(0));
 }
 
 // compute_gray_heating_rate_kernel!, src/optics/GrayAtmosphere.jl:152-167
 template <typename FT>
-__global__ void heating_rate_kernel(int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, FT grav, FT cp_d) {
+__global__ void heating_rate_kernel(int ncol, int nlay, View2<FT> hr_lay, View2<const FT> flux_net, View2<const FT> p_lev,
+                                    FT grav, FT cp_d) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)ncol * nlay) return;
-    const size_t col = i / nlay, k = i - col * nlay, o = (size_t)(nlay + 1) * col + k;
-    hr_lay[i] = grav * (flux_net[o + 1] - flux_net[o]) / (p_lev[o + 1] - p_lev[o]) / cp_d;
+    const int col = (int)(i / nlay), k = (int)(i - (size_t)col * nlay);
+    hr_lay(k, col) = grav * (flux_net(k + 1, col) - flux_net(k, col)) / (p_lev(k + 1, col) - p_lev(k, col)) / cp_d;
 }
 template <typename FT>
-int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, FT *hr_lay, const FT *flux_net, const FT *p_lev, double grav,
-                        double cp_d) {
+int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, View2<FT> hr_lay, View2<const FT> flux_net,
+                        View2<const FT> p_lev, double grav, double cp_d) {
     const size_t n = (size_t)ncol * nlay;
     const int tx = 256;
     hipLaunchKernelGGL((heating_rate_kernel<FT>), dim3((unsigned)((n + tx - 1) / tx)), dim3(tx), 0, ws->stream, ncol, nlay, hr_lay,
@@ -292,8 +297,8 @@ int launch_heating_rate(rrtmgp_workspace *ws, int ncol, int nlay, FT *hr_lay, co
     RR_HIP(hipGetLastError());
     return RRTMGP_OK;
 }
-template int launch_heating_rate<float>(rrtmgp_workspace *, int, int, float *, const float *, const float *, double, double);
-template int launch_heating_rate<double>(rrtmgp_workspace *, int, int, double *, const double *, const double *, double, double);
+template int launch_heating_rate<float>(rrtmgp_workspace *, int, int, View2<float>, View2<const float>, View2<const float>, double, double);
+template int launch_heating_rate<double>(rrtmgp_workspace *, int, int, View2<double>, View2<const double>, View2<const double>, double, double);
 
 template <typename FT>
 int launch_gray_lw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, const GrayArgs &ga, const FT *lat,
@@ -334,8 +339,8 @@ int launch_gray_sw(rrtmgp_workspace *ws, int twostream, int ncol, int nlay, cons
 }
 
 template <typename FT>
-int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, const FT *p_lev, FT *col_dry, const rrtmgp_params &ps,
-                   const FT *vmr_h2o, const FT *lat) {
+int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, View2<const FT> p_lev, View2<FT> col_dry, const rrtmgp_params &ps,
+                   View2<const FT> vmr_h2o, const FT *lat) {
     const size_t n = (size_t)ncol * nlay;
     const int tx = 256;
     hipLaunchKernelGGL((col_gas_kernel<FT>), dim3((unsigned)((n + tx - 1) / tx)), dim3(tx), 0, ws->stream, ncol, nlay, p_lev,
@@ -345,12 +350,12 @@ int launch_col_gas(rrtmgp_workspace *ws, int ncol, int nlay, const FT *p_lev, FT
 }
 
 template <typename FT>
-int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p_lay, const FT *t_lay,
-                   const rrtmgp_params &ps, const FT *vmr_h2o) {
+int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, View2<FT> rh, View2<const FT> p_lay, View2<const FT> t_lay,
+                   const rrtmgp_params &ps, View2<const FT> vmr_h2o) {
     const size_t n = (size_t)ncol * nlay;
     const int tx = 256;
     const FT mwd = (FT)ps.molmass_water / (FT)ps.molmass_dryair;
-    hipLaunchKernelGGL((rel_hum_kernel<FT>), dim3((unsigned)((n + tx - 1) / tx)), dim3(tx), 0, ws->stream, n, rh, p_lay,
+    hipLaunchKernelGGL((rel_hum_kernel<FT>), dim3((unsigned)((n + tx - 1) / tx)), dim3(tx), 0, ws->stream, ncol, nlay, rh, p_lay,
                        t_lay, mwd, vmr_h2o);
     RR_HIP(hipGetLastError());
     return RRTMGP_OK;
@@ -362,10 +367,10 @@ int launch_rel_hum(rrtmgp_workspace *ws, int ncol, int nlay, FT *rh, const FT *p
                                     const DevFlux<FT> &);                                                              \
     template int launch_gray_sw<FT>(rrtmgp_workspace *, int, int, int, const GrayArgs &, const FT *, const FT *,       \
                                     const FT *, const FT *, const FT *, const FT *, const DevFlux<FT> &);              \
-    template int launch_col_gas<FT>(rrtmgp_workspace *, int, int, const FT *, FT *, const rrtmgp_params &, const FT *, \
-                                    const FT *);                                                                       \
-    template int launch_rel_hum<FT>(rrtmgp_workspace *, int, int, FT *, const FT *, const FT *, const rrtmgp_params &, \
-                                    const FT *);
+    template int launch_col_gas<FT>(rrtmgp_workspace *, int, int, View2<const FT>, View2<FT>, const rrtmgp_params &,   \
+                                    View2<const FT>, const FT *);                                                      \
+    template int launch_rel_hum<FT>(rrtmgp_workspace *, int, int, View2<FT>, View2<const FT>, View2<const FT>,         \
+                                    const rrtmgp_params &, View2<const FT>);
 INST(float)
 INST(double)
 

@@ -7,6 +7,14 @@
 // `col_offset` advanced to its first global column (the McICA stream is keyed by the global column), and
 // stages its fluxes back into the caller's arrays.  The public entry points (api.hip) do the slicing and
 // re-enter themselves with a shard workspace; this file owns the objects and the fan-out.
+#include <pthread.h>
+#include <sched.h>
+
+#include <cctype>
+#include <condition_variable>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 #include "common.h"
@@ -21,21 +29,119 @@ const rrtmgp_lookup *lookup_on(const rrtmgp_lookup *lk, int device) {
     return nullptr;
 }
 
-int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, size_t, size_t)> &shard_call) {
+// ---- shard workers ---------------------------------------------------------------------------------------------------
+// One persistent host thread per shard beyond the first (shard 0 runs on the calling thread), parked on a condition
+// variable between calls: a call costs two notifications per shard instead of a thread spawn + join (multi_run used to
+// create and join std::threads on every entry).  A worker is bound to the CPUs that are local to its GPU's PCIe root
+// (/sys/bus/pci/devices/<bus id>/local_cpulist): at 8 GPUs the staging copies of one process move > 100 GB/s, which only
+// works from the memory controllers next to each GPU.  RRTMGP_HIP_NO_NUMA_BIND=1 leaves the threads unbound.
+struct ShardWorkers {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        const std::function<void()> *job = nullptr;  // set by the caller, cleared by the worker when done
+        bool quit = false;
+    };
+    std::vector<std::unique_ptr<Worker>> w;
+
+    static void bind_near(int device) {
+        if (getenv("RRTMGP_HIP_NO_NUMA_BIND")) return;
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+        for (char *c = bus; *c; c++) *c = (char)tolower(*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return;
+        char line[4096] = {0};
+        const bool ok = fgets(line, sizeof line, f) != nullptr;
+        fclose(f);
+        if (!ok) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n = 0;
+        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {  // "0-31,64-95"
+            int lo = 0, hi = 0;
+            const int k = sscanf(tok, "%d-%d", &lo, &hi);
+            if (k < 1) continue;
+            if (k == 1) hi = lo;
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); n++; }
+        }
+        if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);  // failure (cgroup limits) is harmless
+    }
+    explicit ShardWorkers(const std::vector<rrtmgp_workspace *> &shards) {
+        for (size_t s = 1; s < shards.size(); s++) {
+            w.emplace_back(new Worker());
+            Worker *me = w.back().get();
+            const int device = shards[s]->device;
+            me->th = std::thread([me, device] {
+                bind_near(device);
+                std::unique_lock<std::mutex> lk(me->mu);
+                for (;;) {
+                    me->cv.wait(lk, [me] { return me->job || me->quit; });
+                    if (me->quit) return;
+                    const std::function<void()> *j = me->job;
+                    lk.unlock();
+                    (*j)();
+                    lk.lock();
+                    me->job = nullptr;
+                    me->cv.notify_all();
+                }
+            });
+        }
+    }
+    void start(size_t i, const std::function<void()> *job) {
+        std::lock_guard<std::mutex> lk(w[i]->mu);
+        w[i]->job = job;
+        w[i]->cv.notify_all();
+    }
+    void wait(size_t i) {
+        std::unique_lock<std::mutex> lk(w[i]->mu);
+        w[i]->cv.wait(lk, [&] { return w[i]->job == nullptr; });
+    }
+    ~ShardWorkers() {
+        for (auto &x : w) {
+            { std::lock_guard<std::mutex> lk(x->mu); x->quit = true; }
+            x->cv.notify_all();
+            x->th.join();
+        }
+    }
+};
+void shard_workers_destroy(ShardWorkers *p) { delete p; }
+
+int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, size_t, size_t)> &shard_call, bool device_arrays) {
     const size_t n = ws->shards.size();
+    if (device_arrays) {
+        // the shards run on private streams: whatever the caller queued on this device (the producer of the arrays) first
+        RR_HIP(hipSetDevice(ws->shards[0]->device));
+        RR_HIP(hipDeviceSynchronize());
+    }
     std::vector<int> rc(n, RRTMGP_OK);
     std::vector<std::string> msg(n);
     auto run = [&](size_t s) {
         const size_t c0 = (size_t)ws->shard_c0[s], c1 = (size_t)ws->shard_c0[s + 1];
         if (c1 == c0) return;
         rc[s] = shard_call(ws->shards[s], c0, c1 - c0);
-        if (rc[s] != RRTMGP_OK) msg[s] = last_error_string();  // the message lives in the worker's thread-local slot
+        if (rc[s] != RRTMGP_OK) { msg[s] = last_error_string(); return; }  // the message lives in the worker's thread-local slot
+        // host arrays are home already (the shard's entry point blocks); device arrays: the kernels have finished
+        if (device_arrays && hipStreamSynchronize(ws->shards[s]->stream) != hipSuccess) { rc[s] = RRTMGP_EHIP; msg[s] = "hipStreamSynchronize"; }
     };
-    std::vector<std::thread> workers;
-    workers.reserve(n);
-    for (size_t s = 1; s < n; s++) workers.emplace_back(run, s);
-    run(0);
-    for (auto &t : workers) t.join();
+    static const bool spawn = getenv("RRTMGP_HIP_SPAWN_SHARD_THREADS") != nullptr;  // A/B: the old thread-per-call fan-out
+    if (spawn) {
+        std::vector<std::thread> workers;
+        for (size_t s = 1; s < n; s++) workers.emplace_back(run, s);
+        run(0);
+        for (auto &t : workers) t.join();
+    } else {
+        if (!ws->workers && n > 1) ws->workers = new ShardWorkers(ws->shards);
+        std::vector<std::function<void()>> jobs(n);
+        for (size_t s = 1; s < n; s++) {
+            jobs[s] = [&run, s] { run(s); };
+            ws->workers->start(s - 1, &jobs[s]);
+        }
+        run(0);
+        for (size_t s = 1; s < n; s++) ws->workers->wait(s - 1);
+    }
     for (size_t s = 0; s < n; s++)
         if (rc[s] != RRTMGP_OK) return set_error(rc[s], "shard " + std::to_string(s) + ": " + msg[s]);
     return RRTMGP_OK;

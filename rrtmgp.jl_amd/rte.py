@@ -16,7 +16,7 @@ import numpy as np
 from . import _abi, _lib
 from .lookups import GasLookup, LookUpAerosolMerra, LookUpCld
 from .states import (AtmosphericState, Flux, FluxBand, GrayAtmosphericState, LwBCs, SwBCs, array_dtype, array_ptr,
-                     julia_shape)
+                     julia_shape, view2d)
 
 
 def _device_key(device):
@@ -244,50 +244,66 @@ def _check_extents(ws: Workspace, what: str, **arrays):
             continue
         got = tuple(julia_shape(a))
         if got != tuple(want):
-            raise ValueError(f"{what}: {name} has shape {got}, the workspace was created for {tuple(want)}")
+            raise ValueError(f"{what}: {name} has shape {got}, expected {tuple(want)}")
         if np.dtype(array_dtype(a)) != ws.dtype:
             raise TypeError(f"{what}: {name} is {np.dtype(array_dtype(a))}, the workspace was created for {ws.dtype}")
 
 
+def _views(*arrays):
+    """rrtmgp_view2d descriptors (by reference, None -> NULL) of arrays that share one memory kind."""
+    vs, mems = [], set()
+    for a in arrays:
+        v, m = view2d(a)
+        vs.append(v)
+        if m is not None:
+            mems.add(m)
+    if len(mems) != 1:
+        raise ValueError("arrays must all be host or all be device memory")
+    return [None if v is None else C.byref(v) for v in vs], mems.pop(), vs
+
+
 def compute_col_gas(ws: Workspace, p_lev, params, vmr_h2o=None, lat=None, out=None):
-    """compute_col_gas! (src/optics/column_amounts.jl:14-43) on the device."""
+    """compute_col_gas! (src/optics/column_amounts.jl:14-43) on the device.  Like the reference's method the arrays
+    may be strided views: `out = layerdata[0]` of a `(4, nlay, ncol)` array (`getview_col_dry`,
+    AtmosphericStates.jl:96-97), `vmr_h2o = vmr[idx_h2o - 1]` of a full Vmr (grid_adaptation.jl:204)."""
     nlev, ncol = julia_shape(p_lev)
     if out is None:
         out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
-    # the C entry point sizes every copy and launch from the workspace: the arrays must have exactly its extents
-    _check_extents(ws, "compute_col_gas", p_lev=(p_lev, (ws.nlay + 1, ws.ncol)), col_dry=(out, (ws.nlay, ws.ncol)),
-                   vmr_h2o=(vmr_h2o, (ws.nlay, ws.ncol)), lat=(lat, (ws.ncol,)))
-    p, mem = array_ptr(p_lev)
+    _check_extents(ws, "compute_col_gas", col_dry=(out, (nlev - 1, ncol)), vmr_h2o=(vmr_h2o, (nlev - 1, ncol)), lat=(lat, (ncol,)),
+                   p_lev=(p_lev, (nlev, ncol)))
+    (pl, cd, h2o), mem, keep = _views(p_lev, out, vmr_h2o)
     pd = params.desc()
-    _lib.check(_lib.lib().rrtmgp_hip_compute_col_gas(ws.handle, mem, p, array_ptr(out)[0], C.byref(pd),
-                                                     array_ptr(vmr_h2o)[0], array_ptr(lat)[0]), "compute_col_gas")
+    _lib.check(_lib.lib().rrtmgp_hip_compute_col_gas(ws.handle, mem, ncol, nlev - 1, pl, cd, C.byref(pd), h2o,
+                                                     array_ptr(lat)[0]), "compute_col_gas")
     return out
 
 
 def compute_relative_humidity(ws: Workspace, p_lay, t_lay, params, vmr_h2o, out=None):
-    """compute_relative_humidity! (src/optics/column_amounts.jl:52-76) on the device."""
+    """compute_relative_humidity! (src/optics/column_amounts.jl:52-76) on the device; strided views as above
+    (the reference's drivers pass rows 4, 2, 3 of layerdata, test/read_clear_sky.jl:162-169)."""
+    nlay, ncol = julia_shape(p_lay)
     if out is None:
-        out = np.empty(julia_shape(p_lay), dtype=array_dtype(p_lay), order="F")
-    full = (ws.nlay, ws.ncol)
+        out = np.empty((nlay, ncol), dtype=array_dtype(p_lay), order="F")
+    full = (nlay, ncol)
     _check_extents(ws, "compute_relative_humidity", rh=(out, full), p_lay=(p_lay, full), t_lay=(t_lay, full),
                    vmr_h2o=(vmr_h2o, full))
-    p, mem = array_ptr(p_lay)
+    (r, p, t, h), mem, keep = _views(out, p_lay, t_lay, vmr_h2o)
     pd = params.desc()
-    _lib.check(_lib.lib().rrtmgp_hip_compute_relative_humidity(ws.handle, mem, array_ptr(out)[0], p,
-                                                               array_ptr(t_lay)[0], C.byref(pd),
-                                                               array_ptr(vmr_h2o)[0]), "compute_relative_humidity")
+    _lib.check(_lib.lib().rrtmgp_hip_compute_relative_humidity(ws.handle, mem, ncol, nlay, r, p, t, C.byref(pd), h),
+               "compute_relative_humidity")
     return out
 
 
 def compute_gray_heating_rate(ws: Workspace, p_lev, flux_net, cp_d: float, grav: float, out=None):
     """compute_gray_heating_rate! (src/optics/GrayAtmosphere.jl:133-167) on the device:
-    hr(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d."""
+    hr(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d.  `p_lev` / `flux_net` may be the
+    getters' domain views (`x[:nlev_domain]`, src/api/getters.jl:42-43): nlay is then one less than the workspace's."""
     nlev, ncol = julia_shape(p_lev)
     if out is None:
         out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
-    lev = (ws.nlay + 1, ws.ncol)
-    _check_extents(ws, "compute_gray_heating_rate", p_lev=(p_lev, lev), flux_net=(flux_net, lev), hr_lay=(out, (ws.nlay, ws.ncol)))
-    p, mem = array_ptr(p_lev)
-    _lib.check(_lib.lib().rrtmgp_hip_compute_gray_heating_rate(ws.handle, mem, array_ptr(out)[0], p, array_ptr(flux_net)[0],
+    lev = (nlev, ncol)
+    _check_extents(ws, "compute_gray_heating_rate", p_lev=(p_lev, lev), flux_net=(flux_net, lev), hr_lay=(out, (nlev - 1, ncol)))
+    (hr, pl, fn), mem, keep = _views(out, p_lev, flux_net)
+    _lib.check(_lib.lib().rrtmgp_hip_compute_gray_heating_rate(ws.handle, mem, ncol, nlev - 1, hr, pl, fn,
                                                                float(cp_d), float(grav)), "compute_gray_heating_rate")
     return out

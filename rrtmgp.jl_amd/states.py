@@ -14,6 +14,8 @@ An array field is either
 """
 from __future__ import annotations
 
+import os
+import weakref
 from dataclasses import dataclass, fields, replace
 from typing import Optional
 
@@ -26,16 +28,74 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
 
+# ---- page-locked host arrays: explicit lifetime (include/rrtmgp_hip.h, rrtmgp_hip_host_register) -----------------
+# The binding is the owner's agent: a large numpy array is registered the first time it is handed to the library and
+# unregistered by a finalizer on the object that owns its memory (the ultimate `.base`), so a registration can never
+# outlive its pages.  Arrays below 32 MB stay pageable (they share heap pages with other objects: see the header).
+PIN_MIN_BYTES = int(os.environ.get("RRTMGP_HIP_HOST_REGISTER_MIN_BYTES", 32 << 20))
+_PIN_OFF = bool(os.environ.get("RRTMGP_HIP_NO_HOST_REGISTER"))
+_PINNED = {}   # (address, nbytes) of an owner array -> its finalizer
+
+
+def _unpin(key):
+    from . import _lib
+    try:
+        if _PINNED.pop(key, None) is not None:
+            _lib.lib().rrtmgp_hip_host_unregister(key[0])
+    except Exception:   # interpreter shutdown: the library may be gone
+        pass
+
+
+def pin_host_array(a: np.ndarray, min_bytes: Optional[int] = None) -> bool:
+    """Page-lock the memory of `a` (its owner array's whole range) until that owner is garbage-collected.  Idempotent;
+    returns True when the range is (now) registered."""
+    owner = a
+    while isinstance(owner.base, np.ndarray):
+        owner = owner.base
+    if owner.base is not None or owner.nbytes < (PIN_MIN_BYTES if min_bytes is None else min_bytes):
+        return False          # memory owned by something else (a buffer, an mmap), or too small
+    key = (owner.ctypes.data, owner.nbytes)
+    if key in _PINNED:
+        return True
+    from . import _lib
+    if _lib.lib().rrtmgp_hip_host_register(key[0], key[1]) != 0:
+        return False
+    _PINNED[key] = weakref.finalize(owner, _unpin, key)
+    return True
+
+
 def array_ptr(x):
     """(pointer, mem kind) of a field, (None, None) for None."""
     if x is None:
         return None, None
     if isinstance(x, np.ndarray):
+        if not _PIN_OFF and x.nbytes >= PIN_MIN_BYTES:
+            pin_host_array(x)
         return _abi.fptr(x), _abi.MEM_HOST
     if _is_torch(x):
         if not x.is_contiguous():
             raise ValueError("device tensors must be contiguous")
         return x.data_ptr(), (_abi.MEM_DEVICE if x.is_cuda else _abi.MEM_HOST)
+    raise TypeError(f"unsupported array type {type(x)}")
+
+
+def view2d(x):
+    """(rrtmgp_view2d, mem kind) of a 2-D array in Julia index order, dense or strided — a numpy view such as
+    `layerdata[1]` of a (4, nlay, ncol) Fortran array (the reference's `view(as.layerdata, 2, :, :)`), a row of a
+    full Vmr, a domain view `x[:n]`; torch tensors (reversed shape) likewise.  (None, None) for None."""
+    if x is None:
+        return None, None
+    v = _abi.View2D()
+    if isinstance(x, np.ndarray):
+        if x.ndim != 2 or any(s % x.itemsize or s <= 0 for s in x.strides):
+            raise ValueError("expected a 2-D array with positive element strides")
+        v.ptr, v.stride0, v.stride1 = x.ctypes.data, x.strides[0] // x.itemsize, x.strides[1] // x.itemsize
+        return v, _abi.MEM_HOST
+    if _is_torch(x):
+        if x.dim() != 2 or any(s <= 0 for s in x.stride()):
+            raise ValueError("expected a 2-D tensor with positive strides")
+        v.ptr, v.stride0, v.stride1 = x.data_ptr(), x.stride(1), x.stride(0)   # torch shape is the Julia shape reversed
+        return v, (_abi.MEM_DEVICE if x.is_cuda else _abi.MEM_HOST)
     raise TypeError(f"unsupported array type {type(x)}")
 
 

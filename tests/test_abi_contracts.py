@@ -88,12 +88,15 @@ def test_two_workspaces_from_two_host_threads(tables64):
 
 
 def test_only_large_host_arrays_are_page_locked(tables32):
-    """hipHostRegister locks whole pages: only arrays of >= 32 MB (always mmapped: pages of their own) are registered;
-    smaller ones share heap pages with other objects and stay pageable (include/rrtmgp_hip.h; the rule that ended the
-    intermittent GPU memory faults of round 2).  Registrations go away with the workspace."""
+    """hipHostRegister locks whole pages: only arrays of >= 32 MB (always mmapped: pages of their own) are registered —
+    by the BINDING, through rrtmgp_hip_host_register, for the lifetime of the array (include/rrtmgp_hip.h); smaller ones
+    share heap pages with other objects and stay pageable (the rule that ended the intermittent GPU memory faults of
+    round 2).  The registration goes away with the array, not with the workspace."""
+    import gc
     t = tables32
     nlay = 16
     regs = lambda: _lib.allocation_counts()[2]  # noqa: E731
+    live = _lib.lib().rrtmgp_hip_host_registered_count
     # 96 columns: nothing is large enough
     as_, lb, sb = S.make_columns(96, nlay, np.float32, seed=1)
     r0 = regs()
@@ -104,10 +107,109 @@ def test_only_large_host_arrays_are_page_locked(tables32):
     as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=1)
     assert as_.layerdata.nbytes >= 32 << 20 > as_.t_lev.nbytes
     slv = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
-    r1 = regs()
+    r1, n1 = regs(), live()
     rte.solve_lw(slv, as_, t["lw"], t["cld_lw"])
     big = regs() - r1
+    assert live() == n1 + 1
     rte.solve_lw(slv, as_, t["lw"], t["cld_lw"])
     again = regs() - r1 - big
     # (the first small solve of a workspace page-locks its own bounce buffer: counted with the registrations)
     assert small == 1 and big == 1 and again == 0, (small, big, again)
+    del as_
+    gc.collect()
+    assert live() == n1      # released with the array (the workspace is still alive)
+
+
+def test_registered_array_freed_and_reallocated_at_the_same_address(tables32):
+    """A host model that rebinds a fresh same-size state array every step while keeping its workspace: glibc hands the
+    same mmap hole out again, so the new array sits at the address of the old one.  With registrations tied to the
+    array's lifetime the old one is gone before the new one is seen; every solve must read the NEW pages (a stale
+    registration would silently keep the old physical pages mapped for the GPU)."""
+    import gc
+    t = tables32
+    nlay, ncol = 16, 140_000
+    base, lb, _ = S.make_columns(ncol, nlay, np.float32, seed=3)
+    slv = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
+    regs0 = _lib.allocation_counts()[2]
+    addrs, olr = set(), []
+    want = {}
+    for it in range(200):
+        import copy
+        as_ = copy.copy(base)
+        ld = np.array(base.layerdata, order="F", copy=True)       # a fresh 35.8 MB array (mmapped), registered on first use
+        shift = float(it % 4)                                     # four different temperature profiles, cycling
+        ld[2] += shift
+        as_.layerdata = ld
+        addrs.add(ld.ctypes.data)
+        out = rte.solve_lw(slv, as_, t["lw"], t["cld_lw"], seed=5)
+        up = out.as_nlev_ncol("flux_up")[-1, ::4096].copy()
+        if it < 4:
+            want[shift] = up
+        else:
+            np.testing.assert_array_equal(up, want[shift])        # the bits of the first solve with this profile
+        del as_, ld, out
+        gc.collect()
+    assert not np.array_equal(want[0.0], want[1.0])
+    assert len(addrs) < 200, "the allocator never reused an address: the test did not exercise the hazard"
+    assert _lib.allocation_counts()[2] - regs0 >= 100             # re-registered with (nearly) every new array
+    assert _lib.lib().rrtmgp_hip_host_registered_count() <= 2
+
+
+def test_two_workspaces_share_large_registered_arrays_from_two_threads(tables32):
+    """Two workspaces (LW and SW of one model) on two host threads, both reading the SAME >= 32 MB state arrays through the
+    pipelined host path: neither may release or re-register what the other is copying from (the registry used
+    to keep one `verified_by` slot per entry)."""
+    t = tables32
+    nlay, ncol = 16, 140_000
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=2)
+    dl = {k: rte.DeviceLookup(t[k], 0) for k in ("lw", "sw", "cld_lw", "cld_sw")}
+    lw = rte.TwoStreamLWRTE(ncol, nlay, np.float32, lb)
+    sw = rte.TwoStreamSWRTE(ncol, nlay, np.float32, sb)
+    ref_lw = {n: rte.solve_lw(lw, as_, dl["lw"], dl["cld_lw"], seed=7).as_nlev_ncol(n).copy() for n in LWN}
+    ref_sw = {n: rte.solve_sw(sw, as_, dl["sw"], dl["cld_sw"], seed=7).as_nlev_ncol(n).copy() for n in SWN}
+    regs0 = _lib.allocation_counts()[2]
+    errors = []
+
+    def run_lw():
+        try:
+            for _ in range(12):
+                out = rte.solve_lw(lw, as_, dl["lw"], dl["cld_lw"], seed=7)
+                for n in LWN:
+                    np.testing.assert_array_equal(out.as_nlev_ncol(n), ref_lw[n])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def run_sw():
+        try:
+            for _ in range(12):
+                out = rte.solve_sw(sw, as_, dl["sw"], dl["cld_sw"], seed=7)
+                for n in SWN:
+                    np.testing.assert_array_equal(out.as_nlev_ncol(n), ref_sw[n])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=run_lw), threading.Thread(target=run_sw)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert _lib.allocation_counts()[2] == regs0        # nothing was re-registered along the way
+
+
+def test_host_register_contract():
+    """rrtmgp_hip_host_register / _unregister: reference counted per exact range, overlapping ranges of other extents and
+    unknown pointers are refused."""
+    L = _lib.lib()
+    a = np.zeros(40 << 20, dtype=np.uint8)
+    p, n0 = a.ctypes.data, L.rrtmgp_hip_host_registered_count()
+    assert L.rrtmgp_hip_host_register(p, a.nbytes) == 0
+    assert L.rrtmgp_hip_host_register(p, a.nbytes) == 0            # second owner of the same range
+    assert L.rrtmgp_hip_host_registered_count() == n0 + 1
+    assert L.rrtmgp_hip_host_register(p + 4096, a.nbytes - 8192) != 0 and "overlaps" in _lib.last_error()
+    assert L.rrtmgp_hip_host_unregister(p) == 0
+    assert L.rrtmgp_hip_host_registered_count() == n0 + 1
+    assert L.rrtmgp_hip_host_unregister(p) == 0
+    assert L.rrtmgp_hip_host_registered_count() == n0
+    assert L.rrtmgp_hip_host_unregister(p) != 0 and "not a registered range" in _lib.last_error()
+    assert L.rrtmgp_hip_host_register(None, 16) != 0

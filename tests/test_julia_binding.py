@@ -6,6 +6,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from rrtmgp_jl_amd import _abi, _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +16,8 @@ JL = open(os.path.join(ROOT, "ext", "RRTMGPHIPExt.jl")).read()
 PAIRS = {"MinorDesc": _abi.MinorDesc, "GasLookupDesc": _abi.GasLookupDesc, "CloudLookupDesc": _abi.CloudLookupDesc,
          "AerosolLookupDesc": _abi.AerosolLookupDesc, "AtmosStateDesc": _abi.AtmosState, "LwBcsDesc": _abi.LwBcs,
          "SwBcsDesc": _abi.SwBcs, "FluxOutDesc": _abi.FluxOut, "SolveOpts": _abi.SolveOpts,
-         "GrayStateDesc": _abi.GrayState, "ParamsDesc": _abi.Params, "PrepareOpts": _abi.PrepareOpts}
+         "GrayStateDesc": _abi.GrayState, "ParamsDesc": _abi.Params, "PrepareOpts": _abi.PrepareOpts,
+         "View2D": _abi.View2D}
 SIZES = {"Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "P": 8, "Ptr{Int64}": 8, "MinorDesc": C.sizeof(_abi.MinorDesc),
          "NTuple{5, Float64}": 40}
 
@@ -25,6 +28,17 @@ def julia_fields(name):
     for part in re.split(r"[;\n]", body):
         part = part.strip()
         if part:
+            f, t = part.split("::")
+            out.append((f.strip(), t.strip()))
+    return out
+
+
+def julia_fields_of(name):
+    body = re.search(r"^(?:mutable )?struct %s(?: <: [\w.]+)?\n(.*?)^end" % name, JL, flags=re.S | re.M).group(1)
+    out = []
+    for part in re.split(r"[;\n]", body):
+        part = part.split("#")[0].strip()
+        if "::" in part:
             f, t = part.split("::")
             out.append((f.strip(), t.strip()))
     return out
@@ -256,3 +270,73 @@ def test_every_imported_and_qualified_reference_name_exists():
                 missing.append(f"{owner}.{m.group(1)}")
     assert checked >= 40, checked
     assert missing == []
+
+
+# ---- the zero-allocation contract of the per-solve path (test/standalone.jl:361-383), held statically -----------------
+def _hot(src=JL):
+    mod = _module(src)
+    ref_names = {r["name"] for r in SIGS["methods"]}
+    roots = [m for ms in _device_methods(mod).values() for m in ms if m.name.split(".")[-1] in ref_names]
+    assert len(roots) >= 13, [m.name for m in roots]
+    return mod, JLITE.hot_methods(mod, roots)
+
+
+def _allocations(src=JL):
+    _, hot = _hot(src)
+    return [(m.name, what, line) for m in hot for what, line in JLITE.allocating_constructs(m)]
+
+
+def test_no_allocation_on_the_per_solve_path():
+    """No function reachable from the 13 device methods broadcasts, copies a view into an `Array`, builds a `Dict` key,
+    a closure, a `Ref` box or a string — except inside `*_slow` functions (handle creation on the first call, error
+    text), which the walk does not enter.  The round-2 file failed this in five places (`Int32.(dev.ids)`
+    4-5x per solve, `Array(view)` / `copyto!` around compute_col_gas! and compute_relative_humidity!, `get!(...) do`)."""
+    mod, hot = _hot()
+    names = {m.name.split(".")[-1] for m in hot}
+    # the walk is not vacuous: it reaches the cache searches, the descriptors and the view conversion
+    assert {"workspace", "lookup_handle", "state_desc", "flux_desc", "view2d", "opts", "check", "params_desc"} <= names, names
+    assert not any(n.endswith("_slow") for n in names)
+    assert _allocations() == []
+
+
+@pytest.mark.parametrize("old,new,what", [
+    # round 2's `devices(dev)`: a fresh Vector per call
+    ("    c = dev.cache\n    ft = ftype(FT)\n", "    c = dev.cache\n    ft = ftype(FT)\n    ids32 = Int32.(dev.ids)\n", "broadcast `Int32.(...)`"),
+    # round 2's dense copies of the strided arguments
+    ("view2d(a::StridedMatrix) = View2D(ptr(a), stride(a, 1), stride(a, 2))",
+     "view2d(a::StridedMatrix) = View2D(ptr(Array(a)), stride(a, 1), stride(a, 2))", "call of `Array`"),
+    # round 2's `get!(WORKSPACES, (dev.ids, ...)) do ... end`
+    ("    return workspace_create_slow(dev, Int(ncol), Int(nlay), ft)\n",
+     "    return get!(() -> workspace_create_slow(dev, Int(ncol), Int(nlay), ft), TABLE, (dev.ids, ncol, nlay, ft))\n", "call of `get!`"),
+    # an error message built on the hot path
+    ("check(rc::Cint) = rc == 0 ? nothing : fail_slow(rc)", 'check(rc::Cint) = rc == 0 ? nothing : error("status $rc")', "call of `error`"),
+])
+def test_allocation_lint_catches_the_round2_patterns(old, new, what):
+    assert old in JL, old
+    found = {w for _, w, _ in _allocations(JL.replace(old, new, 1))}
+    assert what in found, found
+
+
+def test_strided_views_cross_the_abi_uncopied():
+    """compute_col_gas! / compute_relative_humidity! / compute_gray_heating_rate! hand the reference's views over as
+    (pointer, strides): `view2d` is defined on StridedMatrix, every 2-D array argument of the three ccalls goes through it,
+    and the extents travel with the call."""
+    mod = _module()
+    v = [m for m in mod.methods if m.name == "view2d"]
+    assert {JLITE.norm_type(m.params[0].type) for m in v} == {"StridedMatrix", "Nothing"}
+    body = {m.name.split(".")[-1]: "".join(t.text for t in m.body if t.kind != "nl") for m in mod.methods
+            if m.name.split(".")[-1] in ("compute_col_gas!", "compute_relative_humidity!", "compute_gray_heating_rate!")
+            and m.params and JLITE.norm_type(m.params[0].type) == "HIPDevice"}
+    assert body["compute_col_gas!"].count("view2d(") == 3 and body["compute_relative_humidity!"].count("view2d(") == 4
+    assert body["compute_gray_heating_rate!"].count("view2d(") == 3
+    for b in body.values():
+        assert "ncol,nlay,view2d(" in b and "Array(" not in b and "copyto!" not in b
+
+
+def test_device_owns_its_handles():
+    """`HIPDevice` converts its ids to the ABI's Int32 once and owns a HandleCache; lookups are cached per device set
+    (one global table keyed by the lookup alone served the wrong replica set to a second device)."""
+    fields = dict(julia_fields_of("HIPDevice"))
+    assert fields == {"ids": "Vector{Int32}", "cache": "HandleCache"}, fields
+    assert "const LOOKUPS" not in JL and "const WORKSPACES" not in JL
+    assert re.search(r"lk_table::Vector\{Any\}", JL)        # keeps the key array alive: its address cannot be reused

@@ -1,0 +1,133 @@
+"""compute_col_gas! / compute_relative_humidity! / compute_gray_heating_rate! with the arguments the REFERENCE passes:
+strided views, not dense copies.
+
+  * `update_concentrations!` (src/api/grid_adaptation.jl:278-292) hands over `getview_col_dry(as)` =
+    `view(as.layerdata, 1, :, :)` (element stride 4, AtmosphericStates.jl:96-97) and, for a full `Vmr`,
+    `view(vmr.vmr, idx_h2o, :, :)` (element stride ngas, grid_adaptation.jl:204);
+  * the reference's drivers call `compute_relative_humidity!` on rows 4, 2, 3 of layerdata (test/read_clear_sky.jl:162-169);
+  * `heating_rate` (src/api/standalone.jl:106-122) passes the getters' domain views `view(x, 1:nlev-1, :)` when the grid
+    has an isothermal boundary layer (src/api/getters.jl:42-43).
+
+The C ABI takes these as rrtmgp_view2d (pointer + element strides): nothing is copied on the caller's side and whatever
+else lives in the parent arrays must come back bit-identical."""
+import numpy as np
+import pytest
+
+import rrtmgp_jl_amd  # noqa: F401
+from oracle import oracle as O
+from rrtmgp_jl_amd import _lib, rte, synthetic as S
+from rrtmgp_jl_amd.states import RRTMGPParameters
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(ft, ncol=37, nlay=26, full_vmr=True, seed=5):
+    as_, _, _ = S.make_columns(ncol, nlay, ft, seed=seed, vmr_kind="full" if full_vmr else "gm")
+    return as_
+
+
+@pytest.mark.parametrize("ft,rtol", [(np.float64, 1e-13), (np.float32, 1e-5)])
+@pytest.mark.parametrize("device", [0, [0, 0, 0]])
+def test_col_gas_writes_row_1_of_layerdata_from_a_row_of_vmr(ft, rtol, device):
+    params = RRTMGPParameters()
+    as_ = _state(ft)
+    nlay, ncol = as_.dims
+    ws = rte.Workspace(ncol, nlay, ft, device)
+    ld = as_.layerdata                      # (4, nlay, ncol), Fortran order
+    vmr = as_.vmr.vmr                       # (ngas, nlay, ncol)
+    assert ld.flags.f_contiguous and vmr.flags.f_contiguous and vmr.ndim == 3
+    before = ld.copy(order="F")
+    vmr_before = vmr.copy(order="F")
+    h2o_view, cd_view = vmr[0], ld[0]       # what _vmr_h2o / getview_col_dry return: element strides ngas and 4
+    assert cd_view.strides[0] == 4 * ld.itemsize and h2o_view.strides[0] == vmr.shape[0] * vmr.itemsize
+    want = O.compute_col_gas(as_.p_lev, params, np.asfortranarray(h2o_view), as_.lat)
+    ld[0] = -1.0
+    out = rte.compute_col_gas(ws, as_.p_lev, params, h2o_view, as_.lat, out=cd_view)
+    assert out is cd_view
+    np.testing.assert_allclose(ld[0], want, rtol=rtol)
+    np.testing.assert_array_equal(ld[1:], before[1:])       # p_lay, t_lay, rel_hum untouched
+    np.testing.assert_array_equal(vmr, vmr_before)
+
+
+@pytest.mark.parametrize("ft,rtol", [(np.float64, 1e-12), (np.float32, 2e-5)])
+@pytest.mark.parametrize("device", [0, [0, 0]])
+def test_relative_humidity_on_the_rows_of_layerdata(ft, rtol, device):
+    params = RRTMGPParameters()
+    as_ = _state(ft, full_vmr=False)
+    nlay, ncol = as_.dims
+    ws = rte.Workspace(ncol, nlay, ft, device)
+    ld = as_.layerdata
+    before = ld.copy(order="F")
+    h2o = as_.vmr.vmr_h2o
+    want = O.compute_relative_humidity(np.asfortranarray(ld[1]), np.asfortranarray(ld[2]), params, h2o)
+    ld[3] = -1.0
+    rte.compute_relative_humidity(ws, ld[1], ld[2], params, h2o, out=ld[3])   # three views of ONE parent + a dense array
+    np.testing.assert_allclose(ld[3], want, rtol=rtol)
+    np.testing.assert_array_equal(ld[:3], before[:3])
+
+
+def test_views_in_device_memory():
+    import torch
+    params = RRTMGPParameters()
+    ft = np.float64
+    as_ = _state(ft)
+    nlay, ncol = as_.dims
+    ws = rte.Workspace(ncol, nlay, ft)
+    dev = torch.device("cuda", 0)
+    ld = torch.from_numpy(np.ascontiguousarray(as_.layerdata.T)).to(dev)      # torch shape (ncol, nlay, 4): same bytes
+    vmr = torch.from_numpy(np.ascontiguousarray(as_.vmr.vmr.T)).to(dev)       # (ncol, nlay, ngas)
+    p_lev = torch.from_numpy(np.ascontiguousarray(as_.p_lev.T)).to(dev)
+    lat = torch.from_numpy(as_.lat).to(dev)
+    want = O.compute_col_gas(as_.p_lev, params, np.asfortranarray(as_.vmr.vmr[0]), as_.lat)
+    keep = ld.clone()
+    rte.compute_col_gas(ws, p_lev, params, vmr[:, :, 0], lat, out=ld[:, :, 0])
+    ws.synchronize()
+    np.testing.assert_allclose(ld[:, :, 0].cpu().numpy().T, want, rtol=1e-13)
+    assert torch.equal(ld[:, :, 1:], keep[:, :, 1:])
+    want_rh = O.compute_relative_humidity(np.asfortranarray(as_.layerdata[1]), np.asfortranarray(as_.layerdata[2]), params,
+                                          np.asfortranarray(as_.vmr.vmr[0]))
+    rte.compute_relative_humidity(ws, ld[:, :, 1], ld[:, :, 2], params, vmr[:, :, 0], out=ld[:, :, 3])
+    ws.synchronize()
+    np.testing.assert_allclose(ld[:, :, 3].cpu().numpy().T, want_rh, rtol=1e-12)
+
+
+@pytest.mark.parametrize("device", [0, [0, 0]])
+def test_heating_rate_on_domain_views(device):
+    """The solver's arrays have nlev + 1 levels when there is an isothermal boundary layer; `heating_rate` passes the
+    first nlev of them as views and the domain's layer count: one less than the workspace's."""
+    params = RRTMGPParameters()
+    ft = np.float64
+    ncol, nlay = 19, 31                       # workspace (solver) layers; the domain has nlay - 1
+    as_ = _state(ft, ncol=ncol, nlay=nlay, full_vmr=False)
+    ws = rte.Workspace(ncol, nlay, ft, device)
+    rng = np.random.default_rng(11)
+    fnet = np.asfortranarray(rng.normal(0.0, 40.0, (nlay + 1, ncol)))
+    p_dom, f_dom = as_.p_lev[:nlay], fnet[:nlay]      # _domain_view: rows 1:nlev-1, column stride nlev
+    assert p_dom.strides[1] == (nlay + 1) * 8 and not p_dom.flags.f_contiguous
+    want = O.gray_heating_rate(np.asfortranarray(f_dom), np.asfortranarray(p_dom), params.grav, params.cp_d)
+    hr = rte.compute_gray_heating_rate(ws, p_dom, f_dom, params.cp_d, params.grav)
+    assert hr.shape == (nlay - 1, ncol)
+    np.testing.assert_allclose(hr, want, rtol=1e-13)
+    # into a view as well (a host model's (nlay, ncol) buffer, first nlay - 1 rows)
+    buf = np.full((nlay, ncol), 7.0, order="F")
+    rte.compute_gray_heating_rate(ws, p_dom, f_dom, params.cp_d, params.grav, out=buf[:nlay - 1])
+    np.testing.assert_allclose(buf[:nlay - 1], want, rtol=1e-13)
+    assert np.all(buf[nlay - 1] == 7.0)
+
+
+def test_extents_are_checked():
+    """Round 1's entry points took their sizes from the workspace: a smaller caller array was an out-of-bounds read."""
+    params = RRTMGPParameters()
+    as_ = _state(np.float64, ncol=8, nlay=12, full_vmr=False)
+    small = rte.Workspace(4, 12, np.float64)
+    with pytest.raises(_lib.RRTMGPHipError, match="ncol exceeds"):
+        rte.compute_col_gas(small, as_.p_lev, params)
+    shallow = rte.Workspace(8, 10, np.float64)
+    with pytest.raises(_lib.RRTMGPHipError, match="nlay exceeds"):
+        rte.compute_col_gas(shallow, as_.p_lev, params)
+    sharded = rte.Workspace(16, 12, np.float64, [0, 0])
+    with pytest.raises(_lib.RRTMGPHipError, match="multi-device"):
+        rte.compute_col_gas(sharded, as_.p_lev, params)
+    # fewer columns / layers than the workspace is fine on one device
+    big = rte.Workspace(64, 20, np.float64)
+    np.testing.assert_allclose(rte.compute_col_gas(big, as_.p_lev, params), O.compute_col_gas(as_.p_lev, params), rtol=1e-13)

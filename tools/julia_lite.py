@@ -417,7 +417,9 @@ BASE = {"ccall", "Ref", "Ptr", "Cvoid", "Cint", "Csize_t", "Int32", "Int64", "UI
         "C_NULL", "get", "get!", "ENV", "rand", "enumerate", "Dict", "IdDict", "Tuple", "DataType", "NTuple", "Bool", "Any",
         "AbstractArray", "AbstractMatrix", "Union", "Nothing", "Type", "copyto!", "nameof", "typeof", "finalizer", "parent",
         "PermutedDimsArray", "GC", "undef", "String", "Integer", "atexit", "values", "foreach", "empty!", "Symbol", "zeros",
-        "min", "max", "first", "last", "vec", "Base", "Core", "convert", "ntuple", "all", "any", "isempty"}
+        "min", "max", "first", "last", "vec", "Base", "Core", "convert", "ntuple", "all", "any", "isempty",
+        "AbstractVector", "push!", "WeakRef", "collect", "eachindex", "isbitstype", "fieldnames", "getfield", "isstructtype",
+        "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray"}
 
 
 def _locals_of(m: Method) -> set:
@@ -597,3 +599,69 @@ def bad_field_accesses(m: Method, structs: dict, hints: dict) -> List[Tuple[str,
             continue
         i += 1
     return bad
+
+
+# ---------------------------------------------------------------------------- allocation lint
+# The reference's Layer-2 contract is `@allocated update_fluxes!(solver) == 0` (test/standalone.jl:361-383).  Without a
+# Julia to run, the glue is held to a syntactic rule instead: no function reachable from the device methods may contain
+# a construct that allocates, except functions whose name ends in `_slow` (first-call handle creation, error messages),
+# which the walk does not enter.
+ALLOCATING_CALLS = {
+    "Array", "Vector", "Matrix", "collect", "copy", "deepcopy", "similar", "zeros", "ones", "fill", "Dict", "IdDict", "Set",
+    "string", "repr", "sprint", "unsafe_string", "push!", "pushfirst!", "append!", "resize!", "vcat", "hcat", "cat", "map",
+    "filter", "broadcast", "get!", "error", "print", "println", "Ref", "copyto!", "Tuple", "tuple", "Symbol", "getfield",
+    "fieldnames", "finalizer", "WeakRef", "reshape", "permutedims", "transpose",
+}
+COLD_SUFFIX = "_slow"
+
+
+def allocating_constructs(m: Method) -> List[Tuple[str, int]]:
+    """(what, line) for every construct in the body of `m` that allocates (or only belongs in a cold path)."""
+    toks = [t for t in m.body if t.kind != "nl"]
+    out = []
+    for i, t in enumerate(toks):
+        nxt = toks[i + 1] if i + 1 < len(toks) else None
+        prv = toks[i - 1] if i > 0 else None
+        is_call = nxt is not None and nxt.text == "("
+        if nxt is not None and nxt.text == "{":       # `Ref{T}(...)` constructs, `Ref{T}` alone (a ccall type) does not
+            close = _matching(toks, i + 1)
+            is_call = close + 1 < len(toks) and toks[close + 1].text == "("
+        if t.kind == "id" and t.text in ALLOCATING_CALLS and is_call and not (prv is not None and prv.text == "."):
+            out.append((f"call of `{t.text}`", t.line))
+        elif t.kind == "op" and t.text == "." and nxt is not None and nxt.text == "(" and prv is not None and prv.kind == "id":
+            out.append((f"broadcast `{prv.text}.(...)`", t.line))
+        elif t.kind == "op" and len(t.text) > 1 and t.text.startswith(".") and t.text not in ("...", ".."):
+            out.append((f"broadcast operator `{t.text}`", t.line))
+        elif t.kind == "str":
+            out.append(("string literal", t.line))
+        elif t.kind == "op" and t.text == "[" and (prv is None or not (prv.kind in ("id", "num") or prv.text in (")", "]", "}"))
+                                                   or (prv.kind == "id" and prv.text in ("return", "in", "=", "&&", "||"))):
+            out.append(("array literal / comprehension", t.line))
+        elif (t.kind == "op" and t.text == "->") or (t.kind == "id" and t.text in ("do", "function")):
+            out.append(("closure", t.line))
+    return out
+
+
+def calls_of(m: Method, names: set) -> set:
+    toks = [t for t in m.body if t.kind != "nl"]
+    return {t.text for i, t in enumerate(toks[:-1]) if t.kind == "id" and t.text in names and toks[i + 1].text == "("}
+
+
+def hot_methods(mod: Module, roots: List[Method]) -> List[Method]:
+    """The methods of `mod` reachable from `roots` through calls by name (every method of a called name: dispatch is
+    not resolved), not entering functions whose name ends in `_slow`."""
+    by_name = {}
+    for m in mod.methods:
+        by_name.setdefault(m.name.split(".")[-1], []).append(m)
+    names = set(by_name)
+    seen, order, stack = set(), [], list(roots)
+    while stack:
+        m = stack.pop()
+        if id(m) in seen:
+            continue
+        seen.add(id(m)); order.append(m)
+        for nm in calls_of(m, names):
+            if nm.endswith(COLD_SUFFIX):
+                continue
+            stack.extend(by_name[nm])
+    return order
