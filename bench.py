@@ -44,6 +44,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # FP32 vector peak
 # algorithmic flops per (layer, g-point) cell, n_m = 3 minor contributors
 LW_FLOPS_PER_CELL, SW_FLOPS_PER_CELL = 301.0, 345.0
+# no-scattering LW (rte_lw_noscat_one_angle!, src/rte/longwave_noscat.jl:171-301), same counting convention: the optics and
+# sources of the two-stream figure without lw_2stream_coeffs (2 x 53) and the adding step (22) = 173, plus per quadrature
+# angle and direction tau*Ds, the `fact` branch, the source and the transport + accumulation: 14 flops (+ 1 exp, 1 div)
+LW_NOSCAT_FLOPS_PER_CELL, LW_NOSCAT_FLOPS_PER_ANGLE = 173.0, 28.0
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (datasheet; half the FP32 vector rate of the guide's table)
 
 
 def algorithmic_bytes(nlay, nbnd_lw, nbnd_sw, ft_bytes):
@@ -84,6 +89,16 @@ def parse_args(argv=None):
                          "or as the reference does with a second, cloudless solve.  Not the default workload.")
     ap.add_argument("--tile", type=int, default=1, help="repeat the generated columns this many times on the device "
                                                         "(large single-GPU batches without the host-side generation cost)")
+    ap.add_argument("--lw-solver", choices=["2stream", "noscat"], default="2stream",
+                    help="noscat: NoScatLWRTE (rte_lw_noscat_solve!) with --angles quadrature angles; the SW solver stays "
+                         "two-stream: the reference's clear-sky pairing (test/runtests.jl:54-62)")
+    ap.add_argument("--angles", type=int, default=1, help="Gauss-Jacobi angles of the no-scattering LW solver (1..4)")
+    ap.add_argument("--no-clouds", action="store_true", help="clear sky: no cloud state, no cloud lookups")
+    ap.add_argument("--lw-only", action="store_true", help="a step is the LW solve alone")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong: --ncol-total columns are split over the ranks in contiguous ranges (BASELINE config 4: "
+                         "4096 columns on 1 -> 8 GPUs); weak (default): --ncol columns per rank")
+    ap.add_argument("--ncol-total", type=int, default=4096, help="with --scaling strong: columns of the whole job")
     ap.add_argument("--no-legs", action="store_true", help="only the headline measurement (no variant / host / CPU legs)")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)   # child-process mode: compact JSON, no legs
     return ap.parse_args(argv)
@@ -138,14 +153,23 @@ def main():
             dist.init_process_group(backend)
 
     ft = np.float32 if args.dtype == "f32" else np.float64
+    strong = args.scaling == "strong"
+    if strong:
+        if single or args.tile != 1:
+            raise SystemExit("--scaling strong is the one-process-per-GPU path without --tile")
+        c_lo, c_hi = args.ncol_total * rank // world, args.ncol_total * (rank + 1) // world   # rrtmgp.jl_amd/sharding.py ranges
+        args.ncol = c_hi - c_lo
+        if args.ncol < 1:
+            raise SystemExit("--ncol-total is smaller than the number of ranks")
+    clouds = not args.no_clouds
     ncol0, nlay = args.ncol * (args.gpus if single else 1), args.nlay
     ncol = ncol0 * args.tile
     lw, sw = S.make_gas_lookup("lw", ft), S.make_gas_lookup("sw", ft)
-    cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)
+    cl, cs = (S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)) if clouds else (None, None)
     al = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft) if args.aerosols else None
     asw = S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft) if args.aerosols else None
-    col_offset = rank * ncol
-    as_h, lb_h, sb_h = S.make_columns(ncol0, nlay, ft, seed=2026, col_offset=col_offset, clouds=True,
+    col_offset = c_lo if strong else rank * ncol
+    as_h, lb_h, sb_h = S.make_columns(ncol0, nlay, ft, seed=2026, col_offset=col_offset, clouds=clouds,
                                       cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
     shards = None
     if args.host:
@@ -164,7 +188,10 @@ def main():
     wdev = shards if shards else local_rank
     ws_lw = rte.Workspace(ncol, nlay, ft, wdev)
     ws_sw = rte.Workspace(ncol, nlay, ft, wdev)
-    slv_lw = rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_lw)
+    noscat = args.lw_solver == "noscat"
+    slv_lw = (rte.NoScatLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_lw,
+                              n_gauss_angles=args.angles) if noscat else
+              rte.TwoStreamLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_lw))
     slv_sw = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_sw)
     if args.streams == 1 and not shards:
         slv_lw.ws.use_torch_stream()
@@ -190,8 +217,9 @@ def main():
         one = args.clear_sky_diag == "one-pass"
         rte.solve_lw(slv_lw, as_d, d_lw, d_lw_cld, d_lw_aero, seed=2026, col_offset=col_offset,
                      clear_flux=clr_lw if one else None)
-        rte.solve_sw(slv_sw, as_d, d_sw, d_sw_cld, d_sw_aero, seed=2026, col_offset=col_offset,
-                     clear_flux=clr_sw if one else None)
+        if not args.lw_only:
+            rte.solve_sw(slv_sw, as_d, d_sw, d_sw_cld, d_sw_aero, seed=2026, col_offset=col_offset,
+                         clear_flux=clr_sw if one else None)
 
     def barrier():
         if world > 1:
@@ -232,17 +260,22 @@ def main():
     for _ in range(3):
         step()
         k_lw += slv_lw.ws.last_kernel_ms() / 3
-        k_sw += slv_sw.ws.last_kernel_ms() / 3
+        if not args.lw_only:
+            k_sw += slv_sw.ws.last_kernel_ms() / 3
 
     # sanity: results are finite and physical (never timed)
     up, sdn = torch.as_tensor(slv_lw.flux.flux_up), torch.as_tensor(slv_sw.flux.flux_dn)
     if args.host:
         up, sdn = up.T, sdn.T  # numpy (nlev, ncol) -> (ncol, nlev) like the device tensors
     assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
-    assert bool(torch.isfinite(sdn).all())
+    assert args.lw_only or bool(torch.isfinite(sdn).all())
 
+    lw_cell = (LW_NOSCAT_FLOPS_PER_CELL + LW_NOSCAT_FLOPS_PER_ANGLE * args.angles) if noscat else LW_FLOPS_PER_CELL
+    flops_col = nlay * (lw.n_gpt * lw_cell + (0.0 if args.lw_only else sw.n_gpt * SW_FLOPS_PER_CELL))
+    valu_peak = VALU_PEAK_TFLOPS if args.dtype == "f32" else FP64_VALU_PEAK_TFLOPS
     if rank == 0:
-        value = world * ncol * args.steps / elapsed   # single-process: ncol already is the whole job
+        # weak: every rank solved ncol columns per step; strong: the ranks' ranges add up to --ncol-total
+        value = (args.ncol_total if strong else world * ncol) * args.steps / elapsed   # single-process: ncol already is the whole job
         n_gpus = args.gpus if single else world
         step_ms = None
         if per_step:
@@ -251,7 +284,14 @@ def main():
         if args.leg:   # child-process mode: a compact record for the parent's JSON line
             rec = {"value": value, "unit": "columns/s", "ms_per_step": 1e3 * elapsed / args.steps,
                    "lw_kernel_ms": k_lw, "sw_kernel_ms": k_sw, "ncol": ncol, "dtype": args.dtype,
-                   "library": os.path.basename(_lib.SO_PATH)}
+                   "library": os.path.basename(_lib.SO_PATH),
+                   "valu": {"achieved": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12, "peak": valu_peak, "unit": "TFLOP/s",
+                            "frac": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12 / valu_peak,
+                            "algorithmic_flops_per_column": flops_col}}
+            if noscat or not clouds or args.lw_only:
+                rec["workload"] = (f"{'NoScatLWRTE x ' + str(args.angles) + ' angle(s)' if noscat else 'TwoStreamLWRTE'}"
+                                   f"{'' if args.lw_only else ' + TwoStreamSWRTE'}, {'McICA clouds' if clouds else 'clear sky'}, "
+                                   f"{ncol} x {nlay}")
             if step_ms:
                 rec["min_ms"], rec["median_ms"] = step_ms["min"], step_ms["median"]
                 rec["value_at_min"] = ncol / (step_ms["min"] * 1e-3)
@@ -267,12 +307,13 @@ def main():
         dom = "lw_solve_kernel" if ms_lw >= ms_sw else "sw_solve_kernel"
         dom_ms, dom_bytes = (ms_lw, b_lw) if ms_lw >= ms_sw else (ms_sw, b_sw)
         achieved = dom_bytes * ncol / (dom_ms * 1e-3) / 1e9
-        flops = nlay * (lw.n_gpt * LW_FLOPS_PER_CELL + sw.n_gpt * SW_FLOPS_PER_CELL) * ncol
+        flops = flops_col * ncol
         valu_tflops = flops / ((ms_lw + ms_sw) * 1e-3) / 1e12
         traffic = traffic_source = None
         prof = os.path.join(ROOT, "profiles", "latest.json")
         default_workload = (not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32"
-                            and not args.host and args.clear_sky_diag == "off")
+                            and not args.host and args.clear_sky_diag == "off" and not noscat and clouds and not args.lw_only
+                            and not strong)
         if os.path.exists(prof) and default_workload:
             # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
             # (tools/profile2.sh -> tools/rocprof_summary.py): (2 * FETCH_SIZE + WRITE_SIZE) KB, the factor 2
@@ -297,10 +338,14 @@ def main():
             "unit": "columns/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"all-sky (McICA clouds, cld_frac={args.cld_frac:g}) LW+SW two-stream, "
-                                   f"{ncol // (args.gpus if single else 1)} columns/GPU x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
+            "config": {"workload": (f"all-sky (McICA clouds, cld_frac={args.cld_frac:g})" if clouds else "clear-sky") +
+                                   (f" LW no-scattering ({args.angles} angle(s))" + ("" if args.lw_only else " + SW two-stream")
+                                    if noscat else " LW" + ("" if args.lw_only else "+SW") + " two-stream") + ", " +
+                                   (f"{args.ncol_total} columns split over {world} GPU(s) (strong scaling, BASELINE config 4)"
+                                    if strong else f"{ncol // (args.gpus if single else 1)} columns/GPU") +
+                                   f" x {nlay} layers, {lw.n_gpt}+{sw.n_gpt} g-points, "
                                    f"VmrGM{', MERRA aerosols' if args.aerosols else ''}, "
                                    f"{'HOST arrays staged over PCIe every step' if args.host else 'state resident in HBM'}"
                                    + (f", {len(shards)} shards in one process" if shards else "")
@@ -314,8 +359,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_column": dom_bytes, "kernel_ms": dom_ms,
                          "note": "path is FP32-VALU/transcendental + table-gather bound, not HBM bound (SURVEY F8)"},
-            "valu": {"achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": valu_tflops / VALU_PEAK_TFLOPS,
+            "valu": {"achieved": valu_tflops, "peak": valu_peak, "unit": "TFLOP/s",
+                     "frac": valu_tflops / valu_peak,
                      "algorithmic_flops_per_column": flops / ncol},
             "kernels": {"lw_solve_kernel_ms": ms_lw, "sw_solve_kernel_ms": ms_sw,
                         "lw_bytes_per_column": b_lw, "sw_bytes_per_column": b_sw, "step_bytes_per_column": b_step,
@@ -337,16 +382,25 @@ def main():
                 "aerosols": run_leg("aerosols", ["--aerosols"]),
                 "clear_sky_diag": run_leg("clear_sky_diag", ["--clear-sky-diag", "one-pass"]),
                 "ncol_1048576": run_leg("ncol_1048576", ["--tile", "8", "--steps", "3", "--warmup", "1"]),
+                # BASELINE config 2's solvers and precision at bench size: the reference's clear-sky pairing, Float64
+                "noscat_clear_f64": run_leg("noscat_clear_f64", ["--lw-solver", "noscat", "--angles", "1", "--no-clouds",
+                                                                 "--dtype", "f64", "--nlay", "60"]),
+                "noscat_lw_f32_3angles": run_leg("noscat_lw_f32_3angles", ["--lw-solver", "noscat", "--angles", "3",
+                                                                           "--no-clouds", "--lw-only"]),
+                # BASELINE config 4 at its own size (test/all_sky_with_aerosols_highres_gpu_benchmark.jl:285,321-326):
+                # 4096 columns = 4 per resident workgroup, so the launch is one round of the persistent grid + its tail
+                "config4_4096x72_aerosols": run_leg("config4_4096x72_aerosols", ["--ncol", "4096", "--nlay", "72", "--aerosols",
+                                                                                 "--steps", "50", "--warmup", "5"]),
             }
         # CPU baseline: the plain-C oracle (a port, not the Julia reference) on a bounded sample of
         # the same workload, on this box's host cores.  Rank 0, N = 1 only.
         sample = args.cpu_sample if args.cpu_sample is not None else (512 if world == 1 else 0)
-        if sample > 0 and world == 1:
+        if sample > 0 and world == 1 and not noscat and not args.lw_only and not strong:
             from oracle import oracle as O
             O.lib()
 
             def cpu_run(n):
-                cas, clb, csb = S.make_columns(n, nlay, ft, seed=2026, col_offset=0, clouds=True,
+                cas, clb, csb = S.make_columns(n, nlay, ft, seed=2026, col_offset=0, clouds=clouds,
                                                cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
                 tc = time.perf_counter()
                 O.solve_lw(cas, clb, lw, cl, al, seed=2026)

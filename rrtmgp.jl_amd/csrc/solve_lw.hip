@@ -124,6 +124,7 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
 __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
+    static_assert(TWOSTREAM, "the no-scattering solver is lw_noscat_kernel");
     extern __shared__ __align__(16) char smem[];
     constexpr int CHK = HALF ? CH / 2 : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
@@ -327,74 +328,204 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                     }
                 }
             }
-        } else {
-            // ---- no-scattering: optics sweep, then one down + one up transport per angle
-            //      (longwave_noscat.jl:45-96, 224-301) ----
-            FT inc_prev = FT(0);
-            for (int c = 0; c < nchunk; c++) {
-                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
-                mw.refill(k0);
-                __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                RR_CHUNK_SYNC();
-                for (int kk = 0; kk < kn; kk++) {
-                    const int k = k0 + kk;
-                    FT tau, ssa, gg, pfrac;
-                    lw_layer_optics<FT, false>(a, d, sh, lb, k, kk, d.has_cld && mw.next(k), tau, ssa, gg, pfrac);
-                    const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
-                    const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
-                    const FT lay_src = sh.ch->Blay[kk * NBMAX + lb.ibnd] * pfrac;
-                    FT lev_src;
-                    if (k == 0) {
-                        const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
-                        sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
-                        lev_src = lev_src_dec;
-                    } else {
-                        lev_src = m_sqrt_pos(inc_prev * lev_src_dec);
+        }
+        __syncthreads();
+        store_column(fl_out, sh, d, col, ncol, false, a.lk);
+        if (d.has_cld && a.as.cld_cover && tid == 0) {
+            int n = 0;
+            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
+        }
+    }
+}
+
+// fact of rte_lw_noscat_one_angle! (longwave_noscat.jl:178-180): (1 - t) / tau - t, or its series below tau_thresh.
+// Both forms are evaluated and SELECTED: as a branch (what the ternary on expressions compiles to) every angle of every
+// level becomes its own exec-masked region, and the register allocator spills around them (183 registers at 3 angles).
+template <typename FT>
+__device__ __forceinline__ FT noscat_fact(FT tau_loc, FT trans, FT inv_tau_loc, FT tthresh) {
+    const FT big = (FT(1) - trans) * inv_tau_loc - trans;
+    const FT small = tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
+    return tau_loc > tthresh ? big : small;
+}
+
+// ---- no-scattering longwave: rte_lw_noscat_solve! (ext/cuda/rte_longwave_noscat.jl:54-150; bodies
+// src/rte/longwave_noscat.jl:45-96 multi-angle driver, :171-205 rte_lw_noscat_one_angle!, :224-301 sources) ----------
+// The reference runs, per quadrature angle, a down sweep and an up sweep over optics that a separate pass left in memory.
+// Here ONE top-down sweep fuses gas / cloud / aerosol optics, the Planck sources and the downward transport of ALL
+// angles (the layer's exp(-tau D_s) and source terms are formed once per angle and serve both directions).  What it leaves
+// for the upward transport, I_s[lev] = trans_s I_s[lev-1] + src_up_s, depends on the number of angles:
+//   * one angle: (trans, src_up) per level, and the second sweep is one FMA per level;
+//   * more: (tau, B_lay, B_lev_top) per level, from which the second sweep re-forms exp(-tau D_s) and the source per angle.
+//     Storing 2 values per (level, angle) instead made 3 angles cost twice the time of one: 6 values per level are twice
+//     the sweep-scratch traffic of the two-stream kernel (105 GB per launch of 131 072 columns) and that, not the
+//     arithmetic, set the pace (29.2 ms; tools/experiments/README.md).
+// The flux of a level is sum_s pi w_s I_s, summed over the angles in the lane BEFORE the g-point reduction: one
+// wavefront sum per level whatever the number of angles (the reference accumulates angle by angle).
+// The level source sqrt(inc[k-1] dec[k]) (compute_optical_props.jl:189) couples neighbouring layers, so the downward
+// step of a layer is taken one iteration later, when the layer below has its Planck fraction.
+// NANG: quadrature angles (1..4, AngularDiscretizations.jl:34-63); CA: clouds | aerosols << 1, known at compile time.
+template <typename FT, int NANG, int CA>
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_noscat_kernel(const LwArgs<FT> a) {
+    extern __shared__ __align__(16) char smem[];
+    constexpr int CHK = chunk_layers(CA);
+    ColShared<FT, CHK> sh;
+    ColDims dd = a.dims;
+    dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; dd.diag = 0;
+    DevFlux<FT> fl_out = a.fl;
+    fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+    const ColDims &d = dd;
+    carve_shared(sh, smem, d);
+    const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bool active = tid < a.lk.n_gpt;
+    const int g = active ? tid : a.lk.n_gpt - 1;
+    const LaneBand lb = lane_band(a.lk, g);
+    constexpr bool ONE = NANG == 1;
+    constexpr int NV = ONE ? 2 : 3;  // per level: (trans, src_up), or (tau, B_lay, B_lev_top)
+    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
+    const FT amask = active ? FT(1) : FT(0);
+    const int nchunk = (nlay + CHK - 1) / CHK;
+    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);
+    const FT tthresh = tau_thresh<FT>();
+    FT Ds[NANG], rD[NANG], i2f[NANG];
+#pragma unroll
+    for (int s = 0; s < NANG; s++) { Ds[s] = a.Ds[s]; rD[s] = FT(1) / a.Ds[s]; i2f[s] = Num<FT>::pi() * a.wts[s]; }
+
+    for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
+        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
+        uint64_t m0 = 0, m1 = 0;
+        if (d.has_cld) {
+            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 0);
+            const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
+            const unsigned long long b = __ballot(cloudy);
+            if (lane == 0) sh.misc[wave] = __popcll(b);
+        }
+        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
+        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)a.inc_ld * g] : FT(0);
+        FT *acc = sh.acc + (size_t)wave * nlev * 2;
+        const bool writer = lane == 63;
+        MaskWalk<false> mw(m0, m1, nlay, sh.mask);  // top-down
+
+        // incident intensity inc_flux / pi at every angle (longwave_noscat.jl:245-249)
+        FT I[NANG];
+        FT f = FT(0);
+#pragma unroll
+        for (int s = 0; s < NANG; s++) { I[s] = a.inc_flux ? inc / Num<FT>::pi() : FT(0); f += I[s] * i2f[s]; }
+        {
+            const FT sd = wave_sum_to_lane63(f * amask);
+            if (writer) acc[nlay * 2 + 1] = sd;
+        }
+        // the layer above the current one, waiting for its lower level source
+        FT tr_p[NANG], fa_p[NANG], lay_p = FT(0), dec_p = FT(0);
+#pragma unroll
+        for (int s = 0; s < NANG; s++) { tr_p[s] = FT(1); fa_p[s] = FT(0); }
+        // downward step of layer kp with its lower level source: src = (1 - t) B_lev + 2 fact (B_lay - B_lev), :178-181
+        auto step_down = [&](int kp, FT lev_src) {
+            FT fs = FT(0);
+#pragma unroll
+            for (int s = 0; s < NANG; s++) {
+                I[s] = tr_p[s] * I[s] + ((FT(1) - tr_p[s]) * lev_src + FT(2) * fa_p[s] * (lay_p - lev_src));
+                fs += I[s] * i2f[s];
+            }
+            const FT sd = wave_sum_to_lane63(fs * amask);
+            if (writer) acc[kp * 2 + 1] = sd;
+        };
+        FT sfc_source = FT(0);
+        for (int c = nchunk - 1; c >= 0; c--) {
+            const int k0 = c * CHK, kn = min(CHK, nlay - k0);
+            mw.refill(k0 + kn - 1);
+            RR_CHUNK_SYNC();
+            prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
+            RR_CHUNK_SYNC();
+            for (int kk = kn - 1; kk >= 0; kk--) {
+                const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
+                FT tau, ssa, pfrac;
+                gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
+                // OneScalar: clouds and aerosols add their absorption optical depth (cloud_optics.jl:45, aerosol_optics.jl:45)
+                if (d.has_cld && mw.next(k)) tau += sh.ch->cld[r].x;
+                if (d.has_aero && sh.lay[k].aero_mask) tau += sh.ch->aer[r].x;
+                const FT dec = sh.ch->Blev[r] * pfrac;             // B(t_lev[k]) pfrac[k]
+                const FT inc_k = sh.ch->Blev[r + NBMAX] * pfrac;   // B(t_lev[k+1]) pfrac[k]
+                const FT lay_src = sh.ch->Blay[r] * pfrac;
+                // level source at the top of this layer: sqrt(inc[k] dec[k+1]); the top of the atmosphere keeps inc
+                const FT lev_up = k == nlay - 1 ? inc_k : m_sqrt_pos(inc_k * dec_p);
+                if (k < nlay - 1) step_down(k + 1, lev_up);
+                // (1 - t) / (tau D_s): one reciprocal of tau serves every angle (rD[s] = 1 / D_s)
+                const FT inv_tau = m_rcp(tau);
+#pragma unroll
+                for (int s = 0; s < NANG; s++) {
+                    const FT tau_loc = tau * Ds[s];
+                    const FT trans = m_exp(-tau_loc);
+                    const FT fact = noscat_fact(tau_loc, trans, inv_tau * rD[s], tthresh);
+                    tr_p[s] = trans; fa_p[s] = fact;
+                    if (ONE) {
+                        sw.put(k, 0, trans);
+                        sw.put(k, 1, (FT(1) - trans) * lev_up + FT(2) * fact * (lay_src - lev_up));  // upward source
                     }
-                    sw.put(k, 0, tau);
-                    sw.put(k, 1, lay_src);
-                    sw.put(k, 2, lev_src);
-                    inc_prev = lev_src_inc;
+                }
+                if (!ONE) { sw.put(k, 0, tau); sw.put(k, 1, lay_src); sw.put(k, 2, lev_up); }
+                lay_p = lay_src; dec_p = dec;
+                if (k == 0) {
+                    const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+                    sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;  // compute_optical_props.jl:184-186
                 }
             }
-            sw.put(nlay, 2, inc_prev);
-            const FT tthresh = tau_thresh<FT>();
-            for (int imu = 0; imu < a.n_angles; imu++) {
-                const FT Ds = a.Ds[imu], w_mu = a.wts[imu];
-                const FT i2f = Num<FT>::pi() * w_mu;
-                FT I = a.inc_flux ? inc / Num<FT>::pi() : FT(0);
-                const bool first = imu == 0;
-                {
-                    const FT sd = seg_sum<BAND>(I * i2f * amask);
-                    if (writer) acc[nlay * 2 + 1] = first ? sd : acc[nlay * 2 + 1] + sd;
+        }
+        step_down(0, dec_p);  // lev_source[1] = lev_dec of the first layer
+        // surface: I_up = I_dn (1 - emis) + emis B_sfc (:262-266)
+        {
+            FT fs = FT(0);
+#pragma unroll
+            for (int s = 0; s < NANG; s++) { I[s] = I[s] * (FT(1) - emis) + emis * sfc_source; fs += I[s] * i2f[s]; }
+            const FT su = wave_sum_to_lane63(fs * amask);
+            if (writer) acc[0] = su;
+        }
+        // ---- bottom-up: 16 levels per g-point reduction.  One angle: every scratch load of the batch is in flight before
+        //      the FMA chain.  More: 4 levels at a time (the per-angle exponentials of 16 levels at once do not fit the
+        //      registers: 179 spilled), the compiler barrier keeps the sub-batches from being merged again ----
+        constexpr int SB = ONE ? 16 : 4;
+        for (int kl = 0; kl < nlay; kl += 16) {
+            FT pu[16];
+#pragma unroll
+            for (int j0 = 0; j0 < 16; j0 += SB) {
+                FT X[SB][NV];
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const int k = kl + j0 + j < nlay ? kl + j0 + j : nlay - 1;
+#pragma unroll
+                    for (int v = 0; v < NV; v++) X[j][v] = sw.get(k, v);
                 }
-                for (int k = nlay - 1; k >= 0; k--) {
-                    const FT tau_loc = sw.get(k, 0) * Ds;
-                    const FT trans = m_exp(-tau_loc);
-                    const FT lay_src = sw.get(k, 1), lev_src = sw.get(k, 2);
-                    const FT fact = (tau_loc > tthresh)
-                                        ? ((FT(1) - trans) / tau_loc - trans)
-                                        : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
-                    I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT sd = seg_sum<BAND>(I * i2f * amask);
-                    if (writer) acc[k * 2 + 1] = first ? sd : acc[k * 2 + 1] + sd;
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const bool in = kl + j0 + j < nlay;
+                    FT fs = FT(0);
+                    if (ONE) {
+                        if (in) I[0] = X[j][0] * I[0] + X[j][1];
+                        fs = I[0] * i2f[0];
+                    } else {
+                        const FT tau = X[j][0], lay_src = X[j][1], lev_up = X[j][2];
+                        const FT inv_tau = m_rcp(tau), dl = FT(2) * (lay_src - lev_up);
+#pragma unroll
+                        for (int s = 0; s < NANG; s++) {
+                            const FT tau_loc = tau * Ds[s];
+                            const FT trans = m_exp(-tau_loc);
+                            const FT fact = noscat_fact(tau_loc, trans, inv_tau * rD[s], tthresh);
+                            if (in) I[s] = trans * I[s] + ((FT(1) - trans) * lev_up + fact * dl);
+                            fs += I[s] * i2f[s];
+                        }
+                    }
+                    pu[j0 + j] = in ? fs * amask : FT(0);
                 }
-                I = I * (FT(1) - emis) + emis * sfc_source;
-                {
-                    const FT su = seg_sum<BAND>(I * i2f * amask);
-                    if (writer) acc[0] = first ? su : acc[0] + su;
-                }
-                for (int lev = 1; lev <= nlay; lev++) {
-                    const FT tau_loc = sw.get(lev - 1, 0) * Ds;
-                    const FT trans = m_exp(-tau_loc);
-                    const FT lay_src = sw.get(lev - 1, 1), lev_src = sw.get(lev, 2);
-                    const FT fact = (tau_loc > tthresh)
-                                        ? ((FT(1) - trans) / tau_loc - trans)
-                                        : tau_loc * (FT(1.0 / 2.0) + tau_loc * (-FT(1.0 / 3.0) + tau_loc * FT(1.0 / 8.0)));
-                    I = trans * I + ((FT(1) - trans) * lev_src + FT(2) * fact * (lay_src - lev_src));
-                    const FT su = seg_sum<BAND>(I * i2f * amask);
-                    if (writer) acc[lev * 2] = first ? su : acc[lev * 2] + su;
+                if (!ONE) __builtin_amdgcn_sched_barrier(0);  // nothing moves across: the next sub-batch starts with empty hands
+            }
+            FT wu[4];
+            wave_sum16(pu, wu);
+            if ((lane & 15) == 15) {  // row r holds batch entries j = i + 4 r
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = i + 4 * (lane >> 4);
+                    if (kl + j < nlay) acc[(kl + j + 1) * 2] = wu[i];
                 }
             }
         }
@@ -403,7 +534,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
         if (d.has_cld && a.as.cld_cover && tid == 0) {
             int n = 0;
             for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
-            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
+            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);
         }
     }
 }
@@ -450,12 +581,13 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     const bool diag = fl.clear_up != nullptr;
     d.has_cld = cld != nullptr; d.has_aero = aero != nullptr; d.n_acc = diag ? 4 : 2; d.diag = diag; d.max_int = max_int;
     a.dims = d;
+    RR_CHECK(twostream || (n_angles >= 1 && n_angles <= 4), "n_gauss_angles must be 1..4");
     a.n_angles = twostream ? 1 : n_angles;
     double Ds[4], wts[4];
     angular_discretization(a.n_angles, Ds, wts);
     for (int i = 0; i < a.n_angles; i++) { a.Ds[i] = (FT)Ds[i]; a.wts[i] = (FT)wts[i]; }
     // the variants instantiated with aerosols known at compile time (CA >= 2 below) prepare chunk_layers(CA) layers at a time
-    const bool ca_aero = twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH));
+    const bool ca_aero = (twostream && ((aero && (diag || !fl.band_up)) || (diag && chunk_layers(1, true) != CH))) || (!twostream && aero);
     ColShared<FT, chunk_layers(0)> dummy;
     ColShared<FT, chunk_layers(2)> dummy_aero;
     size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
@@ -469,7 +601,19 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");
     }
-    auto kern = !twostream ? lw_solve_kernel<FT, false, false, false>
+    using Kern = void (*)(const LwArgs<FT>);
+    auto noscat_kernel = [&]() -> Kern {
+        const int ca = (cld ? 1 : 0) | (aero ? 2 : 0);
+#define RR_NOSCAT(N) (ca == 0 ? lw_noscat_kernel<FT, N, 0> : ca == 1 ? lw_noscat_kernel<FT, N, 1> : ca == 2 ? lw_noscat_kernel<FT, N, 2> : lw_noscat_kernel<FT, N, 3>)
+        switch (a.n_angles) {
+            case 1: return RR_NOSCAT(1);
+            case 2: return RR_NOSCAT(2);
+            case 3: return RR_NOSCAT(3);
+            default: return RR_NOSCAT(4);
+        }
+#undef RR_NOSCAT
+    };
+    Kern kern = !twostream ? noscat_kernel()
                 : diag     ? (aero ? lw_solve_kernel<FT, true, false, true, 3> : lw_solve_kernel<FT, true, false, true, 1>)
                 : fl.band_up ? lw_solve_kernel<FT, true, true, false>
                 : (cld && aero) ? lw_solve_kernel<FT, true, false, false, 3>
@@ -478,7 +622,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
     const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
     if (grid < 0) return grid;
-    const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
+    const size_t sweep_bytes = (size_t)grid * d.nlev * (!twostream ? (a.n_angles == 1 ? 2 : 3) : diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
     int rc = scratch_ensure(ws, sweep_bytes + 256);
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
