@@ -513,8 +513,12 @@ double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */
 int rrtmgp_hip_last_error(char *buf, size_t n);
-/* "major.minor.patch" */
+/* "major.minor.patch", followed by " [flags]" when the library was not built as shipped */
 const char *rrtmgp_hip_version(void);
+/* The compile-time switches this library was built with, space separated: "" for the shipped build, "RR_PRECISE_F32"
+ * for the IEEE-Float32 build; anything else (RR_EXP_*, tuning values) marks an experimental build whose results may be
+ * wrong by construction (rrtmgp.jl_amd/csrc/variants.h). */
+const char *rrtmgp_hip_build_flags(void);
 /* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,
  * 1 gas_lookup_desc, 2 cloud_lookup_desc, 3 aerosol_lookup_desc, 4 atmos_state, 5 lw_bcs,
  * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d); -1 otherwise.  Lets a

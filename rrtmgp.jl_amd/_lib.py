@@ -70,6 +70,7 @@ EXPORTS = {
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rrtmgp_hip_version": (C.c_char_p, []),
+    "rrtmgp_hip_build_flags": (C.c_char_p, []),
     "rrtmgp_hip_abi_sizeof": (C.c_int, [C.c_int]),
 }
 

@@ -1764,7 +1764,14 @@ int rrtmgp_hip_last_error(char *buf, size_t n) {
     return RRTMGP_OK;
 }
 
-const char *rrtmgp_hip_version(void) { return "0.1.0"; }
+const char *rrtmgp_hip_build_flags(void) {
+    static const std::string s = [] { std::string f = RR_BUILD_FLAGS; return f.empty() ? f : f.substr(1); }();
+    return s.c_str();
+}
+const char *rrtmgp_hip_version(void) {
+    static const std::string s = std::string("0.3.0") + (*rrtmgp_hip_build_flags() ? std::string(" [") + rrtmgp_hip_build_flags() + "]" : std::string());
+    return s.c_str();
+}
 
 /* sizes of the ABI structs as compiled, for binding self-checks (tests/test_abi.py) */
 int rrtmgp_hip_abi_sizeof(int which) {

@@ -16,10 +16,11 @@
 //  * the g-point lanes then only gather their 8(+8) major coefficients and the
 //    minor coefficients (coalesced: the tables are re-laid-out g-point-innermost),
 //    combine them with the band records read from LDS, and run the vertical
-//    sweeps with 4 values per level in the sweep scratch.
+//    sweeps with 3 values per level in the sweep scratch.
 #pragma once
 
 #include "common.h"
+#include "variants.h"
 
 namespace rrtmgp {
 
@@ -27,16 +28,13 @@ constexpr int CH = 16;  // layers per preparation chunk
 // ... of the kernel variant CA (clouds | aerosols << 1, -1 = run-time flags): the aerosol records would push the LDS
 // of a workgroup past a quarter of the CU's 160 KB (3 resident workgroups instead of 4), so those variants prepare
 // 8 layers at a time
-#ifndef RR_DIAG_MIN_WAVES  // resident waves per SIMD the Float32 clear-sky-diagnostic variants are compiled for
-#define RR_DIAG_MIN_WAVES 3
-#endif
 __host__ __device__ constexpr int chunk_layers(int ca, bool diag = false) {
     return ca >= 2 || (diag && RR_DIAG_MIN_WAVES >= 4) ? CH / 2 : CH;
 }
+// ... of the HALF instances of the main two-stream kernels (shorter chunks where that admits one more workgroup per CU)
+template <typename FT>
+__host__ __device__ constexpr int half_chunk_layers() { return sizeof(FT) == 8 ? RR_F64_HALF_CHUNK : CH / 2; }
 
-#ifndef RR_MIN_WAVES
-#define RR_MIN_WAVES 4  // waves per SIMD the column kernels are register-allocated for
-#endif
 
 // ---- numerics (src/Numerics.jl:24-63), all of the working precision --------------
 template <typename FT> struct Num;
@@ -184,9 +182,6 @@ __device__ __forceinline__ void wave_add_to(FT *slot, FT v) {
     const FT rs = row_sum(v);
     if ((threadIdx.x & 15) == 15) (void)__hip_atomic_fetch_add(slot, rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-#ifndef RR_ACC_ATOMIC
-#define RR_ACC_ATOMIC 1
-#endif
 
 // The flux accumulators are kept per "segment": a whole wave (written by lane 63), or a
 // 16-lane row (written by its lane 15) when per-band fluxes are requested.
@@ -1183,6 +1178,28 @@ struct Sweep {
         return __builtin_nontemporal_load(ptr(lev, a));
 #else
         return *ptr(lev, a);
+#endif
+    }
+    // Three values of one level at once (a = 0, or 3 for the clear-sky twin).  Default: three rows, three 4-byte accesses
+    // per lane.  RR_EXP_SCRATCH_X3 (A/B): the three values of a lane sit next to each other ([level][lane][3] records:
+    // the same bytes and cache lines per wavefront, one 12-byte access per lane instead of three).
+    struct V3 { FT x, y, z; };
+    __device__ __forceinline__ V3 *rec(int lev, int a) const {
+        return reinterpret_cast<V3 *>(base + ((unsigned)(lev * NV + a) * row + 3 * lane));
+    }
+    __device__ __forceinline__ void put3(int lev, int a, FT x, FT y, FT z) const {
+#ifdef RR_EXP_SCRATCH_X3
+        *rec(lev, a) = V3{x, y, z};
+#else
+        put(lev, a, x); put(lev, a + 1, y); put(lev, a + 2, z);
+#endif
+    }
+    __device__ __forceinline__ void get3(int lev, int a, FT &x, FT &y, FT &z) const {
+#ifdef RR_EXP_SCRATCH_X3
+        const V3 v = *rec(lev, a);
+        x = v.x; y = v.y; z = v.z;
+#else
+        x = get(lev, a); y = get(lev, a + 1); z = get(lev, a + 2);
 #endif
     }
 };

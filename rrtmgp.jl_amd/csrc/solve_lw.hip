@@ -123,10 +123,10 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // HALF: the main (no-aerosol) instances once more with 8-layer chunks, for columns whose 16-layer records would push a
 // workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) lw_solve_kernel(const LwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : HALF ? RR_F64_HALF_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     static_assert(TWOSTREAM, "the no-scattering solver is lw_noscat_kernel");
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = HALF ? CH / 2 : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
+    constexpr int CHK = HALF ? half_chunk_layers<FT>() : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -180,9 +180,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             // one adding step for one of the two streams: voff / aoff = its slots in the sweep record / accumulators
             auto adding = [&](FT &alb, FT &sr, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff) {
                 const FT denom = m_rcp(FT(1) - Rdif * alb);  // Eq 10
-                sw.put(kl, voff, Tdif * denom);                        // A
-                sw.put(kl, voff + 1, (Rdif * sr + src_dn) * denom);    // B
-                sw.put(kl, voff + 2, alb);
+                sw.put3(kl, voff, Tdif * denom /* A */, (Rdif * sr + src_dn) * denom /* B */, alb);
 #ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 const FT ss = seg_sum<BAND>(sr * amask);
                 if (writer) acc[kl * NA + aoff] = ss;
@@ -262,8 +260,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
 #pragma unroll
                 for (int j = 0; j < DBT; j++) {
                     const int k = kh - j >= 0 ? kh - j : 0;
-                    A[j] = sw.get(k, 0); B[j] = sw.get(k, 1); AL[j] = sw.get(k, 2);
-                    if (DIAG) { Ac[j] = sw.get(k, 3); Bc[j] = sw.get(k, 4); ALc[j] = sw.get(k, 5); }
+                    sw.get3(k, 0, A[j], B[j], AL[j]);
+                    if (DIAG) sw.get3(k, 3, Ac[j], Bc[j], ALc[j]);
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
@@ -594,9 +592,13 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     // main Float32 instances: 8-layer chunks when that is what keeps 4 workgroups resident per CU (160 KB / 4).  Measured:
     // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80
     static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
-    const bool half = !no_half && sizeof(FT) == 4 && twostream && !diag && !fl.band_up && !aero && d.nlay <= 80 && lds > 40960 &&
-                      carve_shared(dummy_aero, (char *)nullptr, d) <= 40960;
-    if (half) lds = carve_shared(dummy_aero, (char *)nullptr, d);
+    // Float64: the 8-layer instances are compiled for RR_F64_HALF_WAVES waves per SIMD (device.h) and taken when their
+    // records let that many workgroups share the CU's LDS
+    constexpr size_t lds_cap = sizeof(FT) == 4 ? 40960 : (160 * 1024) / RR_F64_HALF_WAVES;
+    ColShared<FT, half_chunk_layers<FT>()> dummy_half;
+    const bool half = !no_half && (sizeof(FT) == 4 ? d.nlay <= 80 : RR_F64_HALF_WAVES > 2) && twostream && !diag && !fl.band_up && !aero &&
+                      lds > lds_cap && carve_shared(dummy_half, (char *)nullptr, d) <= lds_cap;
+    if (half) lds = carve_shared(dummy_half, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");

@@ -90,9 +90,9 @@ constexpr int DB = 16;  // levels per batch of the light sweeps
 // HALF: the main (no-aerosol) instances once more with 8-layer chunks, for columns whose 16-layer records would push a
 // workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : 2)) sw_solve_kernel(const SwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : HALF ? RR_F64_HALF_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
-    constexpr int CHK = HALF ? CH / 2 : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
+    constexpr int CHK = HALF ? half_chunk_layers<FT>() : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
@@ -197,9 +197,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, inv_mu0, Rdir, Tdir, Rdif, Tdif);
                 const FT s_up = Rdir * t.dir_above, s_dn = Tdir * t.dir_above;
                 const FT den = m_rcp(FT(1) - t.beta * Rdif);
-                sw.put(k, voff, Tdif * den);                       // U_{k+1} = A U_k + B
-                sw.put(k, voff + 1, (Rdif * t.delta + s_up) * den);
-                sw.put(k, voff + 2, t.beta);                       // D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
+                // U_{k+1} = A U_k + B,  D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}
+                sw.put3(k, voff, Tdif * den, (Rdif * t.delta + s_up) * den, t.beta);
                 const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
                 t.delta = s_dn + Tdif * den * (t.delta + t.beta * s_up);
                 t.beta = beta_n;
@@ -264,8 +263,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
 #pragma unroll
                 for (int j = 0; j < DBT; j++) {
                     const int k = kl + j < nlay ? kl + j : nlay - 1;
-                    A[j] = sw.get(k, 0); B[j] = sw.get(k, 1); BE[j] = sw.get(k, 2);
-                    if (DIAG) { Ac[j] = sw.get(k, 3); Bc[j] = sw.get(k, 4); BEc[j] = sw.get(k, 5); }
+                    sw.get3(k, 0, A[j], B[j], BE[j]);
+                    if (DIAG) sw.get3(k, 3, Ac[j], Bc[j], BEc[j]);
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions
@@ -398,9 +397,13 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     // main Float32 instances: 8-layer chunks when that is what keeps 4 workgroups resident per CU (160 KB / 4).  Measured:
     // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80
     static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
-    const bool half = !no_half && sizeof(FT) == 4 && twostream && !diag && !fl.band_up && !aero && d.nlay <= 80 && lds > 40960 &&
-                      carve_shared(dummy_aero, (char *)nullptr, d) <= 40960;
-    if (half) lds = carve_shared(dummy_aero, (char *)nullptr, d);
+    // Float64: the 8-layer instances are compiled for RR_F64_HALF_WAVES waves per SIMD (device.h) and taken when their
+    // records let that many workgroups share the CU's LDS
+    constexpr size_t lds_cap = sizeof(FT) == 4 ? 40960 : (160 * 1024) / RR_F64_HALF_WAVES;
+    ColShared<FT, half_chunk_layers<FT>()> dummy_half;
+    const bool half = !no_half && (sizeof(FT) == 4 ? d.nlay <= 80 : RR_F64_HALF_WAVES > 2) && twostream && !diag && !fl.band_up && !aero &&
+                      lds > lds_cap && carve_shared(dummy_half, (char *)nullptr, d) <= lds_cap;
+    if (half) lds = carve_shared(dummy_half, (char *)nullptr, d);
     if (diag) {
         RR_CHECK(twostream && cld, "the one-pass clear-sky diagnostic needs the two-stream solver and a cloud lookup");
         RR_CHECK(!fl.band_up, "per-band fluxes and the one-pass clear-sky diagnostic cannot be combined in one launch");

@@ -31,7 +31,34 @@ def test_struct_mirror_matches_compiled_sizes():
     for i, st in enumerate(_lib.ABI_STRUCTS):
         assert L.rrtmgp_hip_abi_sizeof(i) == C.sizeof(st), st.__name__
     assert L.rrtmgp_hip_abi_sizeof(99) == -1
-    assert L.rrtmgp_hip_version() == b"0.1.0"
+    assert L.rrtmgp_hip_version() == b"0.3.0"       # no " [flags]" suffix: built as shipped
+
+
+def test_shipped_library_is_built_without_experiment_switches():
+    """Timing-only switches (RR_EXP_*) give wrong results by construction.  They compile only with -DRR_EXPERIMENTS
+    (`make variant`), and every library says what it was built with: the shipped one must say nothing, the IEEE-Float32
+    build RR_PRECISE_F32 alone.  Every switch the sources use must be registered in csrc/variants.h, which is what makes
+    it show up in rrtmgp_hip_build_flags()."""
+    import subprocess
+    csrc = os.path.join(ROOT, "rrtmgp.jl_amd", "csrc")
+    assert _lib.lib().rrtmgp_hip_build_flags() == b""
+    precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
+    P = C.CDLL(precise)
+    P.rrtmgp_hip_build_flags.restype = C.c_char_p
+    P.rrtmgp_hip_version.restype = C.c_char_p
+    assert P.rrtmgp_hip_build_flags() == b"RR_PRECISE_F32" and P.rrtmgp_hip_version() == b"0.3.0 [RR_PRECISE_F32]"
+    variants = open(os.path.join(csrc, "variants.h")).read()
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")) and f != "variants.h":
+            used |= set(re.findall(r"\b(RR_EXP_\w+|RR_SCRATCH_NT_\w+|RR_PREP_KK_\w+)\b", open(os.path.join(csrc, f)).read()))
+    assert len(used) >= 12, used
+    for name in used:
+        assert f"#ifdef {name}\n#define RR_HAS_{name}" in variants, f"{name} is used in the sources but not registered in variants.h"
+    # an experiment switch without -DRR_EXPERIMENTS does not compile
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DRR_EXP_NO_MINOR",
+                        "-x", "hip", "--cuda-host-only", os.path.join(csrc, "variants.h")], capture_output=True, text=True)
+    assert r.returncode != 0 and "experiments" in r.stderr, r.stderr[-400:]
 
 
 def test_error_reporting_without_gpu_is_loud():

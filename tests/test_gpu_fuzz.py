@@ -16,16 +16,29 @@ pytestmark = pytest.mark.gpu
 LWN, SWN = ("flux_up", "flux_dn", "flux_net"), ("flux_up", "flux_dn", "flux_net", "flux_dn_dir")
 
 
+_REPORT = os.environ.get("RRTMGP_FUZZ_REPORT")   # file that collects (dtype, what, |diff|, max |flux|) of every comparison
+
+
 def _maxdiff(a, b, names):
     return max(float(np.abs(np.float64(getattr(a, n)) - np.float64(getattr(b, n))).max()) for n in names)
 
 
-@pytest.mark.parametrize("FT,tol_lw,tol_sw", [(np.float64, 1e-8, 1e-8), (np.float32, 2e-3, 3e-2)])
+def _budget(FT, lw: bool, max_flux: float) -> float:
+    """Float64: the summation order over g-points and the regrouped interpolations differ from the oracle's by rounding,
+    and the recurrences carry that through the column: a relative budget, 1e-11 of the largest flux, plus 1e-9 W/m2.
+    Float32 (HIP-F32 against the oracle in Float32 on the same inputs and McICA sample): the reference's own F32
+    ratchet, test/float32_consistency.jl:53-62 — LW 1e-3, SW 3e-2 W/m2."""
+    if FT is np.float64:
+        return 1e-11 * max_flux + 1e-9
+    return 1e-3 if lw else 3e-2
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RRTMGP_FUZZ_CASES", "32"))))
-def test_random_configuration(seed, FT, tol_lw, tol_sw):
+def test_random_configuration(seed, FT):
     from rrtmgp_jl_amd._lib import RRTMGPHipError
     try:
-        _random_configuration(seed, FT, tol_lw, tol_sw)
+        _random_configuration(seed, FT)
     except RRTMGPHipError as e:
         # the one size limit: a column's records must fit the 160 KB LDS (deep Float64 columns in the wide variants:
         # clear-sky twin, per-band accumulators); anything else, or that error on a column of <= 128 layers, is a failure
@@ -36,7 +49,7 @@ def test_random_configuration(seed, FT, tol_lw, tol_sw):
 _LAST = {}
 
 
-def _random_configuration(seed, FT, tol_lw, tol_sw):
+def _random_configuration(seed, FT):
     """Float32 runs are compared with the Float32 oracle on the same Float32 inputs (same McICA sample); the
     budgets are those of tests/test_gpu_parity.py for HIP-F32 vs oracle-F32."""
     rng = np.random.default_rng(1000 + seed)
@@ -50,10 +63,6 @@ def _random_configuration(seed, FT, tol_lw, tol_sw):
     ncol = int(rng.choice([1, 2, 7, 33, 130]))
     nlay = int(rng.choice([2, 3, 15, 16, 17, 31, 47, 63, 64, 65, 80, 127, 128, 129, 143, 192, 193]))
     clouds, aerosols = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-    if nlay > 128:
-        # the summation order over g-points and the regrouped interpolations differ from the oracle's by rounding; the
-        # recurrences carry that through twice as many layers (seed 204: 1.9e-8 on fluxes of 1.3e3 W/m2 at 129 layers)
-        tol_lw, tol_sw = 4 * tol_lw, 4 * tol_sw
     _LAST.clear()
     if nlay > 128 and FT is np.float64:
         _LAST["nlay_deep"] = nlay
@@ -66,26 +75,39 @@ def _random_configuration(seed, FT, tol_lw, tol_sw):
     metric = np.asfortranarray(rng.uniform(0.9, 1.1, (nlay + 1, ncol)).astype(FT)) if rng.integers(0, 2) else None
     kw = dict(seed=int(rng.integers(0, 2**31)), col_offset=int(rng.integers(0, 10**6)), metric_scaling=metric)
     tag = f"{np.dtype(FT).name} seed={seed} ncol={ncol} nlay={nlay} bands={gpb_lw}/{gpb_sw} clouds={clouds} aerosols={aerosols} {vmr_kind}"
+    failures = []
+
+    def check(got, ref, names, what):
+        """max |got - ref| over `names` against the budget of this precision and spectral region"""
+        lw_ = len(names) == 3 and what.startswith("lw")
+        d = max(float(np.abs(np.float64(getattr(got, n)) - np.float64(getattr(ref, n))).max()) for n in names)
+        mx = max(float(np.abs(np.float64(getattr(ref, n))).max()) for n in names)
+        tol = _budget(FT, lw_, mx)
+        if _REPORT:
+            with open(_REPORT, "a") as fh:
+                fh.write(f"{np.dtype(FT).name} {what} {d:.3e} {mx:.3e} {tol:.3e} | {tag}\n")
+        if not d < tol:
+            failures.append((what, d, tol, mx))
     # two-stream, with the clear-sky diagnostic in the same launch when there are clouds
     clr_lw = Flux.allocate(ncol, nlay + 1, FT) if clouds else None
     clr_sw = Flux.allocate(ncol, nlay + 1, FT, sw=True) if clouds else None
     f = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, clear_flux=clr_lw, **kw)
     r_clr = Flux.allocate(ncol, nlay + 1, FT) if clouds else None
     r = O.solve_lw(as_, lb, lw, c_lw, a_lw, clear_flux=r_clr, **kw)
-    assert _maxdiff(f, r, LWN) < tol_lw, tag
+    check(f, r, LWN, "lw_2stream+diag")
     if clouds:
-        assert _maxdiff(clr_lw, r_clr, LWN) < tol_lw, tag
+        check(clr_lw, r_clr, LWN, "lw_clear_diag")
     f = rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, clear_flux=clr_sw, **kw)
     r_clr = Flux.allocate(ncol, nlay + 1, FT, sw=True) if clouds else None
     r = O.solve_sw(as_, sb, sw, c_sw, a_sw, clear_flux=r_clr, **kw)
-    assert _maxdiff(f, r, SWN) < tol_sw, tag
+    check(f, r, SWN, "sw_2stream+diag")
     if clouds:
-        assert _maxdiff(clr_sw, r_clr, SWN) < tol_sw, tag
+        check(clr_sw, r_clr, SWN, "sw_clear_diag")
     # plain two-stream (the compile-time specialised instances) and the no-scattering solvers
-    assert _maxdiff(rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, **kw),
-                    O.solve_lw(as_, lb, lw, c_lw, a_lw, **kw), LWN) < tol_lw, tag
-    assert _maxdiff(rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, **kw),
-                    O.solve_sw(as_, sb, sw, c_sw, a_sw, **kw), SWN) < tol_sw, tag
+    check(rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, FT, lb), as_, lw, c_lw, a_lw, **kw),
+          O.solve_lw(as_, lb, lw, c_lw, a_lw, **kw), LWN, "lw_2stream")
+    check(rte.solve_sw(rte.TwoStreamSWRTE(ncol, nlay, FT, sb), as_, sw, c_sw, a_sw, **kw),
+          O.solve_sw(as_, sb, sw, c_sw, a_sw, **kw), SWN, "sw_2stream")
     # per-band fluxes (any band structure: the lanes are laid out band by band on 16-lane rows)
     from rrtmgp_jl_amd.states import FluxBand
     for sw_ in (False, True):
@@ -94,9 +116,7 @@ def _random_configuration(seed, FT, tol_lw, tol_sw):
         (O.solve_sw if sw_ else O.solve_lw)(as_, bcs, lk, c_, a_, band_flux=ref_b, **kw)
         slv = (rte.TwoStreamSWRTE if sw_ else rte.TwoStreamLWRTE)(ncol, nlay, FT, bcs, n_bnd_band_flux=n_bnd)
         (rte.solve_sw if sw_ else rte.solve_lw)(slv, as_, lk, c_, a_, **kw)
-        for n in LWN:
-            d = float(np.abs(np.float64(getattr(slv.band_flux, n)) - np.float64(getattr(ref_b, n))).max())
-            assert d < (tol_sw if sw_ else tol_lw), (tag, sw_, n, d)
+        check(slv.band_flux, ref_b, LWN, ("sw" if sw_ else "lw") + "_band")
     # the same two-stream solves sharded over three workspaces of one process (ids wrap onto the one GPU)
     if ncol >= 3:
         ws3 = rte.Workspace(ncol, nlay, FT, [0, 0, 0])
@@ -112,10 +132,11 @@ def _random_configuration(seed, FT, tol_lw, tol_sw):
         for n in SWN:
             np.testing.assert_array_equal(many.as_nlev_ncol(n), one.as_nlev_ncol(n), err_msg=tag)
     n_ang = int(rng.integers(1, 5))
-    assert _maxdiff(rte.solve_lw(rte.NoScatLWRTE(ncol, nlay, FT, lb, n_gauss_angles=n_ang), as_, lw, c_lw, a_lw, **kw),
-                    O.solve_lw(as_, lb, lw, c_lw, a_lw, twostream=False, n_gauss_angles=n_ang, **kw), LWN) < tol_lw, tag
-    assert _maxdiff(rte.solve_sw(rte.NoScatSWRTE(ncol, nlay, FT, sb), as_, sw, **kw),
-                    O.solve_sw(as_, sb, sw, twostream=False, **kw), SWN) < tol_sw, tag
+    check(rte.solve_lw(rte.NoScatLWRTE(ncol, nlay, FT, lb, n_gauss_angles=n_ang), as_, lw, c_lw, a_lw, **kw),
+          O.solve_lw(as_, lb, lw, c_lw, a_lw, twostream=False, n_gauss_angles=n_ang, **kw), LWN, f"lw_noscat{n_ang}")
+    check(rte.solve_sw(rte.NoScatSWRTE(ncol, nlay, FT, sb), as_, sw, **kw),
+          O.solve_sw(as_, sb, sw, twostream=False, **kw), SWN, "sw_noscat")
+    assert not failures, (tag, failures)
     if clouds:   # identical McICA sample: cloud cover equals the oracle's
         ref = S.make_columns(ncol, nlay, FT, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
                              n_bnd_lw=n_bnd, n_bnd_sw=n_bnd, night_fraction=0.3, random_cld_frac=True)[0]

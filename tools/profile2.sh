@@ -10,7 +10,7 @@ mkdir -p $OUT
 if [ "$VAR" != base ]; then export RRTMGP_HIP_LIBRARY=$REPO/rrtmgp.jl_amd/variants/$VAR.so; fi
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-legs ${BENCH_ARGS:-}"   # BENCH_ARGS: another workload, e.g. "--lw-solver noscat --no-clouds"
-SEL="--kernel-include-regex solve_kernel"
+SEL="--kernel-include-regex (solve|noscat)_kernel"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 PASSES=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
         "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"

@@ -38,14 +38,14 @@ def to_json(root, path, sha=None):
     tr = os.path.join(root, "trace", "bench_results.db")
     if os.path.exists(tr):
         for name, calls, tot, avg, pct in q(tr, "select name, total_calls, total_duration, average, percentage from top_kernels"):
-            for key in ("lw_solve_kernel", "sw_solve_kernel"):
+            for key in ("lw_solve_kernel", "sw_solve_kernel", "lw_noscat_kernel"):
                 if key in name:
                     out["kernels"].setdefault(key, {})["avg_us"] = avg
                     out["kernels"][key]["calls"] = calls
     for d in sorted(glob.glob(os.path.join(root, "pmc_*", "bench_results.db"))):
         for k, c, s, n in q(d, "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
-                               "where kernel_name like '%solve_kernel%' group by kernel_name, counter_name"):
-            for key in ("lw_solve_kernel", "sw_solve_kernel"):
+                               "where (kernel_name like '%solve_kernel%' or kernel_name like '%noscat_kernel%') group by kernel_name, counter_name"):
+            for key in ("lw_solve_kernel", "sw_solve_kernel", "lw_noscat_kernel"):
                 if key in k:
                     out["kernels"].setdefault(key, {})[c] = s / n
     with open(path, "w") as fh:
@@ -61,13 +61,13 @@ def main(root):
             print(f"{name[:90]:90s} {calls:6d} {tot:14.1f} {avg:12.1f} {pct:7.2f}")
         print("\n## dispatch geometry: name, grid, workgroup, lds_size, vgpr, accum_vgpr, sgpr, scratch")
         for r in q(tr, "select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
-                       "from kernels where name like '%solve_kernel%' group by name"):
+                       "from kernels where (name like '%solve_kernel%' or name like '%noscat_kernel%') group by name"):
             print("  ", tuple(x if not isinstance(x, str) else x[:60] for x in r))
     print("\n## PMC passes (--pmc ...): kernel, counter, per-launch average, launches")
     for d in sorted(glob.glob(os.path.join(root, "pmc_*", "bench_results.db"))):
         for k, c, s, n in q(d, "select kernel_name, counter_name, sum(value), count(*) from counters_collection "
-                               "where kernel_name like '%solve_kernel%' group by kernel_name, counter_name"):
-            print(f"{k[:48]:48s} {c:24s} {s / n:20.1f} {n:4d}")
+                               "where (kernel_name like '%solve_kernel%' or kernel_name like '%noscat_kernel%') group by kernel_name, counter_name"):
+            print(f"{k.replace('void rrtmgp::', '')[:56]:56s} {c:28s} {s / n:20.1f} {n:4d}")
 
 
 if __name__ == "__main__":
