@@ -385,6 +385,19 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
     TRY(upload(lk, row_lo, &g.band_row_lo));
     TRY(upload(lk, lane_gpt, &g.band_lane_gpt));
     TRY(upload(lk, ks, &g.key_species));
+    {   // the reference-ratio of the two key species of a band, vmr_ref[tropo, ig0 + 1, jT] / vmr_ref[tropo, ig1 + 1, jT]
+        // (compute_interp_frac_eta, gas_optics.jl:140-143): formed once here, in FT with the IEEE division of the reference's
+        // CPU path, instead of per (layer, band, T plane) on the device
+        const FT *vr = (const FT *)d->vmr_ref;
+        std::vector<FT> eh((size_t)2 * NB * NT);
+        for (int tropo = 0; tropo < 2; tropo++)
+            for (int64_t b = 0; b < NB; b++)
+                for (int64_t t = 0; t < NT; t++) {
+                    const int ig0 = ks[0 + 2 * (tropo + 2 * b)], ig1 = ks[1 + 2 * (tropo + 2 * b)];
+                    eh[((size_t)tropo * NB + b) * NT + t] = vr[tropo + 2 * (ig0 + d->n_gases * t)] / vr[tropo + 2 * (ig1 + d->n_gases * t)];
+                }
+        TRY(upload(lk, eh, &g.eta_half));
+    }
     TRY(upload(lk, g2b, &g.gpt2bnd));
     TRY(upload(lk, lo, &g.bnd_lo));
     TRY(upload(lk, ng, &g.bnd_ng));

@@ -42,6 +42,7 @@ struct DevGas {
     const FT *ln_p_ref;    // [n_p_ref]
     const FT *t_ref;       // [n_t_ref]
     const FT *vmr_ref;     // (2, n_gases, n_t_ref) as the reference stores it
+    const FT *eta_half;    // [tropo][bnd][n_t_ref]: vmr_ref ratio of the band's two key species (gas_optics.jl:140-143)
     const int *key_species;  // (2, 2, n_bnd), gas indices as in the reference
     const int *gpt2bnd;      // [n_gpt] 0-based band
     const int *bnd_lo;       // [n_bnd] first g-point (0-based) of the band

@@ -328,7 +328,7 @@ struct ColShared {
     uint64_t *mask;      // McICA masks of columns with more than 128 layers and clouds: [word][256 lanes], else unused
     // TabCache: the small lookup tables the preparation steps index with data-dependent positions, copied once per
     // workgroup (not per column) so that those dependent reads are LDS round trips instead of L2 ones
-    FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_vmr_ref;
+    FT *tab_t_ref, *tab_ln_p_ref, *tab_t_planck, *tab_eta_half;
     FT *tab_vmr_gm;  // VmrGM: the well-mixed vector, [ngas1] with entry 0 = 1 (it does not depend on the column)
     int *tab_key_species, *tab_gasdata[2], *tab_slot_int[2];
 };
@@ -361,7 +361,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base
     s.tab_t_ref = carve<FT>(p, d.n_t_ref);
     s.tab_ln_p_ref = carve<FT>(p, d.n_p_ref);
     s.tab_t_planck = carve<FT>(p, d.lw ? d.n_t_plnk : 0);
-    s.tab_vmr_ref = carve<FT>(p, (size_t)2 * d.n_gases_ref * d.n_t_ref);
+    s.tab_eta_half = carve<FT>(p, (size_t)2 * d.nbnd * d.n_t_ref);
     s.tab_vmr_gm = carve<FT>(p, d.ngas1);
     s.tab_key_species = carve<int>(p, 4 * d.nbnd);
     s.tab_gasdata[0] = carve<int>(p, 4 * (d.nint0 > 0 ? d.nint0 : 1));
@@ -381,14 +381,14 @@ __device__ inline DevGas<FT> cache_small_tables(const ColShared<FT, CHK> &sh, co
     for (int i = tid; i < d.n_t_ref; i += nt) sh.tab_t_ref[i] = lk.t_ref[i];
     for (int i = tid; i < d.n_p_ref; i += nt) sh.tab_ln_p_ref[i] = lk.ln_p_ref[i];
     if (d.lw) for (int i = tid; i < d.n_t_plnk; i += nt) sh.tab_t_planck[i] = lk.t_planck[i];
-    for (int i = tid; i < 2 * d.n_gases_ref * d.n_t_ref; i += nt) sh.tab_vmr_ref[i] = lk.vmr_ref[i];
+    for (int i = tid; i < 2 * d.nbnd * d.n_t_ref; i += nt) sh.tab_eta_half[i] = lk.eta_half[i];
     for (int i = tid; i < 4 * d.nbnd; i += nt) sh.tab_key_species[i] = lk.key_species[i];
     for (int i = tid; i < 4 * d.nint0; i += nt) sh.tab_gasdata[0][i] = lk.m_gasdata[0][i];
     for (int i = tid; i < 4 * d.nint1; i += nt) sh.tab_gasdata[1][i] = lk.m_gasdata[1][i];
     for (int i = tid; i < d.nslot0; i += nt) sh.tab_slot_int[0][i] = lk.m_slot_int[0][i];
     for (int i = tid; i < d.nslot1; i += nt) sh.tab_slot_int[1][i] = lk.m_slot_int[1][i];
     DevGas<FT> v = lk;
-    v.t_ref = sh.tab_t_ref; v.ln_p_ref = sh.tab_ln_p_ref; v.vmr_ref = sh.tab_vmr_ref;
+    v.t_ref = sh.tab_t_ref; v.ln_p_ref = sh.tab_ln_p_ref; v.eta_half = sh.tab_eta_half;
     if (d.lw) v.t_planck = sh.tab_t_planck;
     v.key_species = sh.tab_key_species;
     v.m_gasdata[0] = sh.tab_gasdata[0]; v.m_gasdata[1] = sh.tab_gasdata[1];
@@ -711,8 +711,7 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
         FT fe[2], cm[2];
 #pragma unroll
         for (int it = 0; it < 2; it++) {
-            const FT eta_half = lk.vmr_ref[tropo + 2 * (ig0 + lk.n_gases * (jT + it))] /
-                                lk.vmr_ref[tropo + 2 * (ig1 + lk.n_gases * (jT + it))];
+            const FT eta_half = lk.eta_half[(tropo * nb + b) * lk.n_t_ref + jT + it];  // vmr_ref ratio of the key species
             const FT col_mix = vmr1 + eta_half * vmr2;
             FT eta = vmr1 * (FT(1) / col_mix);
             if (col_mix <= FT(0)) eta = FT(0.5);
