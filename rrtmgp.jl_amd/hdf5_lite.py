@@ -182,10 +182,20 @@ class Dataset:
                 self._layout = body
             elif mtype == 0x0B:
                 self._filters = _parse_filters(body)
+            elif mtype in (0x04, 0x05):
+                self._fill_raw = _parse_fill_value(mtype, body) or getattr(self, "_fill_raw", None)
 
     @property
     def dtype(self):
         return self._dt.dtype if self._dt else None
+
+    def _blank(self, shape, dt) -> np.ndarray:
+        """What unwritten elements read as: the dataset's fill value (messages 0x05 / 0x04; netCDF-C stores `_FillValue`
+        or its type default there), 0 when none is defined — as libhdf5, h5py and netCDF4 return them."""
+        raw = getattr(self, "_fill_raw", None)
+        if raw is None or len(raw) != dt.itemsize:
+            return np.zeros(shape, dtype=dt)
+        return np.full(shape, np.frombuffer(raw, dtype=dt, count=1)[0], dtype=dt)
 
     @property
     def attrs(self) -> Dict[str, object]:
@@ -250,8 +260,8 @@ class Dataset:
         raise HDF5Error(f"{self.name}: layout message version {ver}")
 
     def _contiguous(self, addr, n, dt, shape):
-        if addr == UNDEF or addr is None:          # never written: fill value (0)
-            return np.zeros(shape, dtype=dt)
+        if addr == UNDEF or addr is None:          # never written: the fill value
+            return self._blank(shape, dt)
         a = self._f.base + addr
         return np.frombuffer(self._f.buf, dtype=dt, count=n, offset=a).reshape(shape).copy()
 
@@ -274,6 +284,9 @@ class Dataset:
         return raw
 
     def _place(self, out, chunk_dims, offs, raw, dt):
+        want = int(np.prod(chunk_dims)) * dt.itemsize
+        if len(raw) != want:
+            raise HDF5Error(f"{self.name}: a chunk decodes to {len(raw)} bytes, expected {want} (truncated or corrupt file)")
         c = np.frombuffer(raw, dtype=dt, count=int(np.prod(chunk_dims))).reshape(chunk_dims)
         sl_out = tuple(slice(o, min(o + cd, s)) for o, cd, s in zip(offs, chunk_dims, out.shape))
         sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
@@ -281,7 +294,7 @@ class Dataset:
 
     def _chunked_v1(self, btree, chunk_dims, dt, shape):
         f = self._f
-        out = np.zeros(shape, dtype=dt)
+        out = self._blank(shape, dt)
         if btree == UNDEF:
             return out
         rank = len(chunk_dims)
@@ -312,7 +325,7 @@ class Dataset:
         dims = [r.u(enc) for _ in range(rank)]
         chunk_dims = dims[:-1]
         itype = r.u(1)
-        out = np.zeros(shape, dtype=dt)
+        out = self._blank(shape, dt)
         nbytes = int(np.prod(chunk_dims)) * dt.itemsize
         nchunks_dim = [(s + c - 1) // c for s, c in zip(shape, chunk_dims)]
         nchunks = int(np.prod(nchunks_dim))
@@ -384,6 +397,27 @@ class Dataset:
                     d.p = start + n_in * esize + 4
             return out
         raise HDF5Error(f"{self.name}: chunk index type {itype} (extensible array / v2 B-tree) is not supported")
+
+
+def _parse_fill_value(mtype: int, b: bytes) -> Optional[bytes]:
+    """Raw bytes of a defined fill value: message 0x05 (versions 1-3) or the old message 0x04; None when undefined."""
+    if mtype == 0x04:
+        size = int.from_bytes(b[0:4], "little")
+        return bytes(b[4:4 + size]) if size else None
+    ver = b[0]
+    if ver in (1, 2):
+        defined = b[3]
+        if ver == 1 or defined:
+            size = int.from_bytes(b[4:8], "little")
+            return bytes(b[8:8 + size]) if size else None
+        return None
+    if ver == 3:
+        flags = b[1]
+        if flags & 0x20:
+            size = int.from_bytes(b[2:6], "little")
+            return bytes(b[6:6 + size]) if size else None
+        return None
+    return None
 
 
 def _parse_filters(b: bytes) -> List[Tuple[int, Tuple[int, ...]]]:

@@ -135,3 +135,70 @@ def test_convert_rrtmgp_data_directory_of_netcdf4_files(tmp_path):
     netcdf_io.convert_rrtmgp_data(str(d), out)
     got = netcdf_io.load_lookups(out)
     assert np.array_equal(got["lw"].kmajor, lw.kmajor) and np.array_equal(got["sw"].kmajor, sw.kmajor)
+
+
+@pytest.mark.skipif(not W.available(), reason="libhdf5 not available")
+@pytest.mark.parametrize("libver", [("earliest", "v18"), ("v18", "latest")])
+def test_unwritten_elements_read_as_the_fill_value(tmp_path, libver):
+    """Partially written and never-written variables: netCDF4 / h5py return the dataset's fill value for what was not
+    written (netCDF-C stores `_FillValue`, or the type's default fill, in the HDF5 fill-value message); the reader used to
+    return 0.  Written with the real libhdf5: a chunked variable with only its first chunk written, a
+    contiguous variable that was never written, and one without a defined fill value (reads 0)."""
+    import ctypes as C
+    h5 = W.H5()
+    L = h5.L
+    hs = W.hsize_t
+    L.H5Pset_fill_value.restype, L.H5Pset_fill_value.argtypes = C.c_int, [W.hid_t, W.hid_t, C.c_void_p]
+    L.H5Sselect_hyperslab.restype = C.c_int
+    L.H5Sselect_hyperslab.argtypes = [W.hid_t, C.c_int, C.POINTER(hs), C.POINTER(hs), C.POINTER(hs), C.POINTER(hs)]
+    path = str(tmp_path / "fill.nc")
+    w = W.NC4Writer(path, libver=libver, h5=h5)
+    f4 = h5.types[np.dtype("f4")]
+    fill = np.array([9.96921e36], dtype="f4")                     # NC_FILL_FLOAT
+
+    def create(name, shape, chunks, with_fill):
+        dcpl = w._dcpl(shape, chunks, 0, False, False)
+        if with_fill:
+            h5.ok(L.H5Pset_fill_value(dcpl, f4, fill.ctypes.data_as(C.c_void_p)), "H5Pset_fill_value")
+        d = (hs * len(shape))(*shape)
+        s = L.H5Screate_simple(len(shape), d, None)
+        ds = h5.ok(L.H5Dcreate2(w.fid, name.encode(), f4, s, 0, dcpl, 0), name)
+        L.H5Pclose(dcpl)
+        return ds, s
+
+    ds, fs = create("partial", (6, 8), (3, 4), True)
+    block = np.arange(12, dtype="f4").reshape(3, 4) + 1
+    start, count = (hs * 2)(0, 0), (hs * 2)(3, 4)
+    h5.ok(L.H5Sselect_hyperslab(fs, 0, start, None, count, None), "hyperslab")
+    ms = L.H5Screate_simple(2, (hs * 2)(3, 4), None)
+    h5.ok(L.H5Dwrite(ds, f4, ms, fs, 0, block.ctypes.data_as(C.c_void_p)), "partial write")
+    for h in (ms, fs):
+        L.H5Sclose(h)
+    L.H5Dclose(ds)
+    for name, shape, chunks, with_fill in (("never", (5,), None, True), ("never_chunked", (4, 4), (2, 2), True),
+                                           ("no_fill", (3,), None, False)):
+        ds, fs = create(name, shape, chunks, with_fill)
+        L.H5Sclose(fs)
+        L.H5Dclose(ds)
+    L.H5Fclose(w.fid)
+
+    f = hdf5_lite.File(path)
+    got = f["partial"][()]
+    want = np.full((6, 8), fill[0], dtype="f4")
+    want[:3, :4] = block
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(f["never"][()], np.full(5, fill[0], dtype="f4"))
+    np.testing.assert_array_equal(f["never_chunked"][()], np.full((4, 4), fill[0], dtype="f4"))
+    np.testing.assert_array_equal(f["no_fill"][()], np.zeros(3, dtype="f4"))
+
+
+def test_truncated_chunk_is_reported(tmp_path):
+    """A chunk that decodes to the wrong number of bytes must raise HDF5Error, not an opaque numpy error."""
+    src = os.path.join(GOLD, "nc4_features_v0.nc")
+    f = hdf5_lite.File(src)
+    name = next(n for n in EXPECTED.files if f[n]._filters and f[n].shape)
+    ds = f[name]
+    orig = ds._decode_chunk
+    ds._decode_chunk = lambda raw, mask, dt, nbytes: orig(raw, mask, dt, nbytes)[:-3]
+    with pytest.raises(hdf5_lite.HDF5Error, match="truncated or corrupt"):
+        ds[()]
