@@ -129,3 +129,27 @@ def test_bench_single_process_fan_out_on_one_gpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["ncol_per_gpu"] == 4096 and "ONE host process" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_mode_on_one_gpu():
+    """BASELINE config 4 is a STRONG-scaling case (4096 columns on 1 -> 8 GPUs): `--scaling strong --ncol-total N` splits the
+    job's columns over the ranks in contiguous ranges; value = total columns per second.  Two ranks share the one GPU of
+    the test box over gloo (bench.py test hook); 4097 columns so that the ranges are ragged (2048 + 2049)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RRTMGP_BENCH_BACKEND="gloo", RRTMGP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--ncol-total", "4097",
+                        "--nlay", "72", "--aerosols", "--cpu-sample", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "4097 columns split over 2 GPU(s)" in d["config"]["workload"]
+    assert abs(d["value"] - 4097 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
