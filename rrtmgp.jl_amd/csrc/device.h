@@ -904,10 +904,16 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
         G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
     } else {
+#ifdef RR_EXP_LW_K_ONLY  // timing-only: 4-byte gathers of k alone at the pairs' addresses (the Planck fraction copies k)
+        auto one = [](const char *bb, unsigned o) { const FT v = ldg<FT>(bb, o); return V2<FT>{v, v}; };
+        const V2<FT> a = one(b0, o1), b = one(b1, o1), c = one(b2, o1), d = one(b3, o1);
+        const V2<FT> e = one(b0, o2), f = one(b1, o2), g = one(b2, o2), h = one(b3, o2);
+#else
         const V2<FT> a = ldg<V2<FT>>(b0, o1), b = ldg<V2<FT>>(b1, o1);
         const V2<FT> c = ldg<V2<FT>>(b2, o1), d = ldg<V2<FT>>(b3, o1);
         const V2<FT> e = ldg<V2<FT>>(b0, o2), f = ldg<V2<FT>>(b1, o2);
         const V2<FT> g = ldg<V2<FT>>(b2, o2), h = ldg<V2<FT>>(b3, o2);
+#endif
         G.k000 = a.x; G.k100 = b.x; G.k010 = c.x; G.k110 = d.x; G.q000 = e.x; G.q100 = f.x; G.q010 = g.x; G.q110 = h.x;
         G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
         G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
@@ -982,11 +988,13 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
     if (G.two) {
         consume(G.g1, G.s1);
         const char *kmn = lk.arena;
+#ifndef RR_EXP_NO_MINOR_TAIL  // timing-only: no third-and-later groups (wrong for bands with more than 8 minor gases)
         for (int i0 = 2 * MINOR_GROUP; i0 < G.n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases (rare; exposed)
             const unsigned x1 = G.a1 + __umul24((unsigned)(i0 / MINOR_GROUP), G.gstep), x2 = x1 - G.a1 + G.a2;
             const Corners<FT> c{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + G.ncb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + G.ncb, x2)};
             consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0));
         }
+#endif
     }
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
     // cm (1-fP) (1-fT) ((1-fe) k000 + fe k100) + ... regrouped as amp * (w11 k000 + w21 k100) + ...
