@@ -131,3 +131,35 @@ def test_extents_are_checked():
     # fewer columns / layers than the workspace is fine on one device
     big = rte.Workspace(64, 20, np.float64)
     np.testing.assert_allclose(rte.compute_col_gas(big, as_.p_lev, params), O.compute_col_gas(as_.p_lev, params), rtol=1e-13)
+
+
+def test_malformed_views_are_refused():
+    """Status codes, not crashes: null pointer, non-positive strides, null view where one is required."""
+    import ctypes as C
+    from rrtmgp_jl_amd import _abi
+    L = _lib.lib()
+    ws = rte.Workspace(8, 12, np.float64)
+    p_lev = np.asfortranarray(np.linspace(1e5, 1e3, 13)[:, None] * np.ones((1, 8)))
+    out = np.zeros((12, 8), order="F")
+    pd = RRTMGPParameters().desc()
+
+    def view(a, s0=None, s1=None, null=False):
+        v = _abi.View2D()
+        v.ptr = None if null else a.ctypes.data
+        v.stride0 = a.strides[0] // 8 if s0 is None else s0
+        v.stride1 = a.strides[1] // 8 if s1 is None else s1
+        return v
+
+    def call(pl, cd, h2o=None):
+        return L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 8, 12, C.byref(pl), C.byref(cd), C.byref(pd),
+                                            None if h2o is None else C.byref(h2o), None)
+
+    assert call(view(p_lev), view(out)) == 0
+    assert call(view(p_lev, null=True), view(out)) != 0 and "null pointer or non-positive stride" in _lib.last_error()
+    assert call(view(p_lev, s0=0), view(out)) != 0
+    assert call(view(p_lev), view(out, s1=-12)) != 0
+    # an absent optional array may be a NULL view or a view with a null pointer (what a binding that always passes a struct does)
+    assert call(view(p_lev), view(out), view(out, null=True)) == 0
+    assert L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 8, 12, None, C.byref(view(out)), C.byref(pd), None, None) != 0
+    assert L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 0, 12, C.byref(view(p_lev)), C.byref(view(out)), C.byref(pd),
+                                        None, None) != 0
