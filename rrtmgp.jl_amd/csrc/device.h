@@ -876,7 +876,11 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     GasLoads<FT, SW> G;
     const LayerRec<FT> &L = sh.lay[k];
     const int li = L.idx;
+#ifdef RR_EXP_FAKE_ROWS  // timing-only: the (T, p) row part of every gather address is dropped (bounds what precomputed offsets could save)
+    const unsigned jT = 0, jP = 0, tropo = li >> 16;
+#else
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
+#endif
     G.fP = L.fP;
     G.ray_fac = SW ? L.ray_fac : FT(0);
     const int r = kk * NBMAX + lb.ibnd;
