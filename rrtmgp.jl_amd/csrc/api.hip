@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 
 #include "common.h"
@@ -1244,7 +1245,7 @@ static int stage_views(Stager &st, int mem, ViewArg *a, int n, size_t E) {
     RR_CHECK(n <= 4, "internal: too many view arguments");
     int order[4], m = 0;
     for (int i = 0; i < n; i++) if (a[i].v) order[m++] = i;
-    std::sort(order, order + m, [&](int x, int y) { return a[x].lo() < a[y].lo(); });
+    std::sort(order, order + m, [&](int x, int y) { return std::less<const char *>()(a[x].lo(), a[y].lo()); });
     for (int i = 0, g = 0; i < m; g++) {
         const char *lo = a[order[i]].lo(), *hi = lo + a[order[i]].span(E);
         int j = i + 1;

@@ -51,8 +51,8 @@ template <> struct Num<double> {
 // square roots are the 2.5-ulp forms (Makefile: -fno-hip-fp32-correctly-rounded-divide-sqrt) and
 // 1 - e^{-x} is evaluated by exp_pair below (<= 1.6 ulp).  Measured against the Float64 oracle
 // the broadband fluxes are as accurate as with the correctly rounded forms ("Float32
-// numerics"); build with -DRR_PRECISE_F32 (and without the flag) to get the latter.  Float64 is
-// always correctly rounded libm.
+// numerics"); build with -DRR_PRECISE_F32 (and without the flag) to get the latter.  Float64 uses
+// libm and IEEE division throughout, except exp_pair below (one argument reduction for both results).
 #ifdef RR_PRECISE_F32
 __device__ __forceinline__ float m_exp(float x) { return expf(x); }
 #else
@@ -92,10 +92,56 @@ template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT
 
 // e1 = exp(-x) and om1 = 1 - exp(-x) for x >= 0: the pair the two-stream coefficients need
 // (e1 = exp(-tau k), om1 = -expm1(-tau k); longwave_2stream.jl:167-168, shortwave_2stream.jl:204-209).
+// Float64: exp(-x) and 1 - exp(-x) from ONE argument reduction (libm's exp + expm1 are two, ~75 FP64 instructions
+// together; this is ~25).  x = n ln2 + r with |r| <= ln2 / 2, p = expm1(-r) by a degree-13 polynomial (next term
+// 0.347^14 / 14! = 4e-18), e^-x = 2^-n (1 + p); 1 - e^-x is -p itself when n = 0 (no cancellation for small x, which is
+// what expm1 is for) and 1 - e^-x otherwise (e^-x <= 0.71 there).  Error <= 2 ulp on both results for x >= 0; x beyond
+// ~745 gives exactly (0, 1) like libm.  RR_PRECISE_F32 builds keep libm.
+// (1 - e^-r) for |r| <= ln2 / 2, and the reduction x = n ln2 + r of a non-negative x
+__device__ __forceinline__ double exp_reduce(double x, int &ni) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);   // x / ln 2
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);  // ln2_hi (the low 21 bits are zero: n * ln2_hi is exact)
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);         // ln2_lo
+    // q = (1 - e^-r) / r = 1 - r/2 + r^2/6 - ... , Horner
+    double q = 1.0 / 87178291200.0;                                // 1/14!
+    q = __builtin_fma(q, -r, 1.0 / 6227020800.0);
+    q = __builtin_fma(q, -r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, -r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, -r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, -r, 1.0 / 362880.0);
+    q = __builtin_fma(q, -r, 1.0 / 40320.0);
+    q = __builtin_fma(q, -r, 1.0 / 5040.0);
+    q = __builtin_fma(q, -r, 1.0 / 720.0);
+    q = __builtin_fma(q, -r, 1.0 / 120.0);
+    q = __builtin_fma(q, -r, 1.0 / 24.0);
+    q = __builtin_fma(q, -r, 1.0 / 6.0);
+    q = __builtin_fma(q, -r, 0.5);
+    q = __builtin_fma(q, -r, 1.0);
+    ni = (int)__builtin_fmin(n, 2000.0);
+    return r * q;                                                  // (may be slightly negative: r in [-ln2/2, ln2/2])
+}
 __device__ __forceinline__ void exp_pair(double x, double &e1, double &om1) {
+#ifdef RR_PRECISE_F32
     e1 = exp(-x);
     om1 = -expm1(-x);
+#else
+    int ni;
+    const double m = exp_reduce(x, ni);
+    e1 = __builtin_ldexp(1.0 - m, -ni);                            // 2^-n e^-r
+    om1 = ni == 0 ? m : 1.0 - e1;
+#endif
 }
+// e^-y for y >= 0 (transmissivities, the direct beam): the same reduction in Float64, the fast / libm exp in Float32
+__device__ __forceinline__ double m_exp_neg(double y) {
+#ifdef RR_PRECISE_F32
+    return exp(-y);
+#else
+    int ni;
+    const double m = exp_reduce(y, ni);
+    return __builtin_ldexp(1.0 - m, -ni);
+#endif
+}
+__device__ __forceinline__ float m_exp_neg(float y) { return m_exp(-y); }
 __device__ __forceinline__ void exp_pair(float x, float &e1, float &om1) {
 #ifdef RR_PRECISE_F32
     e1 = expf(-x);

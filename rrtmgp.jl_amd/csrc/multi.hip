@@ -60,7 +60,8 @@ struct ShardWorkers {
         cpu_set_t set;
         CPU_ZERO(&set);
         int n = 0;
-        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {  // "0-31,64-95"
+        char *save = nullptr;
+        for (char *tok = strtok_r(line, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {  // "0-31,64-95"
             int lo = 0, hi = 0;
             const int k = sscanf(tok, "%d-%d", &lo, &hi);
             if (k < 1) continue;

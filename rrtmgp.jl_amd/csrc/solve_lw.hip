@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
 #pragma unroll
                 for (int s = 0; s < NANG; s++) {
                     const FT tau_loc = tau * Ds[s];
-                    const FT trans = m_exp(-tau_loc);
+                    const FT trans = m_exp_neg(tau_loc);
                     const FT fact = noscat_fact(tau_loc, trans, inv_tau * rD[s], tthresh);
                     tr_p[s] = trans; fa_p[s] = fact;
                     if (ONE) {
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
 #pragma unroll
                         for (int s = 0; s < NANG; s++) {
                             const FT tau_loc = tau * Ds[s];
-                            const FT trans = m_exp(-tau_loc);
+                            const FT trans = m_exp_neg(tau_loc);
                             const FT fact = noscat_fact(tau_loc, trans, inv_tau * rD[s], tthresh);
                             if (in) I[s] = trans * I[s] + ((FT(1) - trans) * lev_up + fact * dl);
                             fs += I[s] * i2f[s];

@@ -40,7 +40,7 @@ __device__ __forceinline__ void sw_2stream_coeffs(FT tau, FT ssa, FT g, FT mu0, 
     FT RT_term = m_rcp(k * (FT(1) + exp_minus2ktau) + gamma1 * one_minus_e2kt);
     Rdif = RT_term * gamma2 * one_minus_e2kt;
     Tdif = RT_term * FT(2) * k * exp_minusktau;
-    const FT T0 = m_exp(-(tau * inv_mu0));
+    const FT T0 = m_exp_neg(tau * inv_mu0);
     FT k_mu = k * mu0;
     FT k_mu2 = k_mu * k_mu;
     const FT diff = FT(1) - k_mu2;
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                     const int k = k0 + kk;
                     FT tau, ssa, pf;
                     gas_optics<FT, true>(a.lk, sh, lb, k, kk, nb, tau, ssa, pf);
-                    dir = dir * m_exp(-tau / m_max(mu0, mu0_min<FT>()));
+                    dir = dir * m_exp_neg(tau / m_max(mu0, mu0_min<FT>()));
                     const FT s = seg_sum<BAND>(dir * amask);
                     if (writer) { acc[k * 3] = FT(0); acc[k * 3 + 1] = s; acc[k * 3 + 2] = s; }
                 }
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             auto layer = [&](Stream &t, FT tau, FT ssa, FT gg, int k, int voff, int aoff, FT &Rdir, FT &Tdir, FT &Rdif,
                              FT &Tdif, bool recompute) {
                 t.tau_cum += tau;
-                const FT dir_k = dir_top * m_exp(-t.tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
+                const FT dir_k = dir_top * m_exp_neg(t.tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
                 if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, inv_mu0, Rdir, Tdir, Rdif, Tdif);
                 const FT s_up = Rdir * t.dir_above, s_dn = Tdir * t.dir_above;
                 const FT den = m_rcp(FT(1) - t.beta * Rdif);
