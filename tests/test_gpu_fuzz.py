@@ -25,11 +25,16 @@ def _maxdiff(a, b, names):
 
 def _budget(FT, lw: bool, max_flux: float) -> float:
     """Float64: the summation order over g-points and the regrouped interpolations differ from the oracle's by rounding,
-    and the recurrences carry that through the column: a relative budget, 1e-11 of the largest flux, plus 1e-9 W/m2.
+    and the recurrences carry that through the column: a RELATIVE budget plus 1e-9 W/m2.  LW (and every no-scattering
+    solver): 1e-11 of the largest flux (observed over 500 random cases: 5e-15).  SW two-stream: 3e-11 — this kernel closes
+    the adding relations from the top of the atmosphere while the oracle (like the reference) adds from the surface up
+    (DESIGN.md section 5, item 5); the two are algebraically identical but amplify rounding by different condition numbers
+    where layers scatter almost conservatively, and in deep aerosol-laden columns that shows: seed 204 (129 layers, MERRA
+    aerosols, no clouds) differs by 1.9e-8 on 1.49e3 W/m2 = 1.25e-11, the largest of 500 cases (all others < 3e-13).
     Float32 (HIP-F32 against the oracle in Float32 on the same inputs and McICA sample): the reference's own F32
-    ratchet, test/float32_consistency.jl:53-62 — LW 1e-3, SW 3e-2 W/m2."""
+    ratchet, test/float32_consistency.jl:53-62 — LW 1e-3, SW 3e-2 W/m2 (observed: 5.7e-4 / 6.7e-3)."""
     if FT is np.float64:
-        return 1e-11 * max_flux + 1e-9
+        return (1e-11 if lw else 3e-11) * max_flux + 1e-9
     return 1e-3 if lw else 3e-2
 
 
