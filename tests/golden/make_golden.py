@@ -56,6 +56,10 @@ def run(case, solve_lw, solve_sw):
                      twostream=two, seed=11)
         tag = "lw2s" if two else "lwns"
         out[f"{tag}_up"], out[f"{tag}_dn"] = f.as_nlev_ncol("flux_up"), f.as_nlev_ncol("flux_dn")
+    # no-scattering with 3 Gauss-Jacobi angles (AngularDiscretizations.jl:47-49; longwave_noscat.jl:45-96)
+    f = solve_lw(as_, lb, t["lw"], t["cld_lw"] if clouds else None, t["aero_lw"] if c["aero"] else None,
+                 twostream=False, seed=11, n_gauss_angles=3)
+    out["lwns3_up"], out["lwns3_dn"] = f.as_nlev_ncol("flux_up"), f.as_nlev_ncol("flux_dn")
     f = solve_sw(as_, sb, t["sw"], t["cld_sw"] if clouds else None, t["aero_sw"] if c["aero"] else None, seed=11)
     out["sw_up"], out["sw_dn"], out["sw_dir"] = (f.as_nlev_ncol(n) for n in ("flux_up", "flux_dn", "flux_dn_dir"))
     if clouds:

@@ -37,6 +37,16 @@ def test_numpy_restatement_agrees_with_golden(case):
     up, dn = NP.solve_lw_noscat(t["lw"], as_, lb, cl)
     np.testing.assert_allclose(up, exp["lwns_up"], rtol=1e-11, atol=1e-10)
     np.testing.assert_allclose(dn, exp["lwns_dn"], rtol=1e-11, atol=1e-10)
+    # three Gauss-Jacobi-5 angles (literal table of src/optics/AngularDiscretizations.jl:47-49): the flux is the
+    # weighted sum of the one-angle solves (longwave_noscat.jl:45-96)
+    mu3 = (0.1024922169, 0.4417960320, 0.8633751621)
+    w3 = (0.0437820218, 0.3875796738, 0.5686383044)
+    up = dn = 0.0
+    for mu, w in zip(mu3, w3):
+        u, d = NP.solve_lw_noscat(t["lw"], as_, lb, cl, Ds=1.0 / mu, w=w)
+        up, dn = up + u, dn + d
+    np.testing.assert_allclose(up, exp["lwns3_up"], rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(dn, exp["lwns3_dn"], rtol=1e-11, atol=1e-10)
     up, dn, dr = NP.solve_sw_2stream(t["sw"], as_, sb, cs)
     np.testing.assert_allclose(up, exp["sw_up"], rtol=1e-11, atol=1e-10)
     np.testing.assert_allclose(dn, exp["sw_dn"], rtol=1e-11, atol=1e-10)
@@ -48,10 +58,10 @@ def test_numpy_restatement_agrees_with_golden(case):
 def test_hip_reproduces_golden(case):
     from rrtmgp_jl_amd import rte
 
-    def lw(as_, bcs, lk, cld, aero, twostream, seed):
+    def lw(as_, bcs, lk, cld, aero, twostream, seed, n_gauss_angles=1):
         nlay, ncol = as_.dims
         cls = rte.TwoStreamLWRTE if twostream else rte.NoScatLWRTE
-        return rte.solve_lw(cls(ncol, nlay, as_.dtype, bcs), as_, lk, cld, aero, seed=seed)
+        return rte.solve_lw(cls(ncol, nlay, as_.dtype, bcs, n_gauss_angles=n_gauss_angles), as_, lk, cld, aero, seed=seed)
 
     def sw(as_, bcs, lk, cld, aero, seed):
         nlay, ncol = as_.dims
