@@ -340,3 +340,21 @@ def test_device_owns_its_handles():
     assert fields == {"ids": "Vector{Int32}", "cache": "HandleCache"}, fields
     assert "const LOOKUPS" not in JL and "const WORKSPACES" not in JL
     assert re.search(r"lk_table::Vector\{Any\}", JL)        # keeps the key array alive: its address cannot be reused
+
+
+def test_allocation_lint_fails_on_the_round2_file():
+    """tests/golden/RRTMGPHIPExt_round2.jl is this repository's own extension as round 2 left it (git ecb1d6f).  The lint
+    must find what the review found there: a fresh `Int32.(dev.ids)` in `devices`, called from every lookup / workspace
+    search of every solve; `Array(view)` + `copyto!` around the three view-taking methods; `get!(...) do` with a freshly
+    built tuple key."""
+    old = open(os.path.join(ROOT, "tests", "golden", "RRTMGPHIPExt_round2.jl")).read()
+    found = _allocations(old)
+    by_fn = {}
+    for fn, what, _ in found:
+        by_fn.setdefault(fn.split(".")[-1], set()).add(what)
+    assert "broadcast `Int32.(...)`" in by_fn.get("devices", ()), by_fn
+    for fn in ("compute_col_gas!", "compute_relative_humidity!", "compute_gray_heating_rate!"):
+        assert "call of `Array`" in by_fn.get(fn, ()) and "call of `copyto!`" in by_fn.get(fn, ()), (fn, by_fn.get(fn))
+    assert "call of `get!`" in by_fn.get("workspace", ()) and "closure" in by_fn.get("workspace", ()), by_fn.get("workspace")
+    assert "call of `get!`" in by_fn.get("lookup_handle", ()), by_fn.get("lookup_handle")
+    assert len(found) >= 20, len(found)
