@@ -808,7 +808,11 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
             if (sh.lay[k].aero_mask) {
                 const size_t o = (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
                 FT ta, tsa, tsga;
+#ifdef RR_EXP_AERO_CONST  // timing-only: no species loop / table lookups (bounds what hoisting them out of the band tasks could save)
+                ta = as.aero_mass[o] + FT(1e-3); tsa = FT(0.5) * ta; tsga = FT(0.25) * ta;
+#else
                 lookup_aerosol(*aero, sh, as.aero_mass + o, as.aero_size + o, b, k, ta, tsa, tsga);
+#endif
                 if (!d.lw && b == aero->iband_550nm - 1) { sh.lay[k].aod_t = ta; sh.lay[k].aod_ts = tsa; }
                 if (d.twostream) {  // aerosol_optics.jl:113-122
                     FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);

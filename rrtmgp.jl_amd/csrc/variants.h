@@ -183,7 +183,13 @@
 #else
 #define RR_HAS_RR_EXP_FAKE_ROWS ""
 #endif
-#define RR_BUILD_FLAGS (RR_HAS_RR_F64_HALF_CHUNK RR_HAS_RR_EXP_FAKE_ROWS RR_HAS_RR_EXP_NO_MINOR_TAIL RR_HAS_RR_EXP_LW_K_ONLY RR_BUILD_FLAGS_PRECISE RR_HAS_RR_EXP_NO_CHUNK_BARRIER RR_HAS_RR_EXP_NO_LAYER_SUMS RR_HAS_RR_EXP_PREP_ONCE RR_HAS_RR_EXP_PREP_SAME_LANES RR_HAS_RR_PREP_KK_MINOR RR_HAS_RR_EXP_NO_MINOR RR_HAS_RR_EXP_ZERO_G1 RR_HAS_RR_EXP_MINOR_ONE_GROUP RR_HAS_RR_EXP_REFILL_SELECT RR_HAS_RR_EXP_MASK_128_ONLY RR_HAS_RR_EXP_SCRATCH_ROW0 RR_HAS_RR_EXP_SCRATCH_ROW0_STORES RR_HAS_RR_EXP_SCRATCH_ROW0_LOADS RR_HAS_RR_SCRATCH_NT_STORE RR_HAS_RR_SCRATCH_NT_LOAD RR_HAS_RR_EXP_SW_256 RR_HAS_RR_EXP_SCRATCH_X3 RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES)
+#ifdef RR_EXP_AERO_CONST
+#define RR_HAS_RR_EXP_AERO_CONST " RR_EXP_AERO_CONST"
+#define RR_ANY_EXPERIMENT 1
+#else
+#define RR_HAS_RR_EXP_AERO_CONST ""
+#endif
+#define RR_BUILD_FLAGS (RR_HAS_RR_F64_HALF_CHUNK RR_HAS_RR_EXP_AERO_CONST RR_HAS_RR_EXP_FAKE_ROWS RR_HAS_RR_EXP_NO_MINOR_TAIL RR_HAS_RR_EXP_LW_K_ONLY RR_BUILD_FLAGS_PRECISE RR_HAS_RR_EXP_NO_CHUNK_BARRIER RR_HAS_RR_EXP_NO_LAYER_SUMS RR_HAS_RR_EXP_PREP_ONCE RR_HAS_RR_EXP_PREP_SAME_LANES RR_HAS_RR_PREP_KK_MINOR RR_HAS_RR_EXP_NO_MINOR RR_HAS_RR_EXP_ZERO_G1 RR_HAS_RR_EXP_MINOR_ONE_GROUP RR_HAS_RR_EXP_REFILL_SELECT RR_HAS_RR_EXP_MASK_128_ONLY RR_HAS_RR_EXP_SCRATCH_ROW0 RR_HAS_RR_EXP_SCRATCH_ROW0_STORES RR_HAS_RR_EXP_SCRATCH_ROW0_LOADS RR_HAS_RR_SCRATCH_NT_STORE RR_HAS_RR_SCRATCH_NT_LOAD RR_HAS_RR_EXP_SW_256 RR_HAS_RR_EXP_SCRATCH_X3 RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES)
 #if defined(RR_ANY_EXPERIMENT) && !defined(RR_EXPERIMENTS)
 #error "RR_EXP_* / tuning switches are experiments: build them with `make variant NAME=... EXTRA=...` (adds -DRR_EXPERIMENTS), never into the shipped library"
 #endif
