@@ -194,14 +194,27 @@ def update_fluxes(s: RRTMGPSolver, seedval=None):
 
 
 # ---- getters (src/api/getters.jl; names of public.jl:96-118) ----------------------------------------
-def lw_flux_up(s): return s.lws.flux.flux_up
-def lw_flux_dn(s): return s.lws.flux.flux_dn
-def lw_flux_net(s): return s.lws.flux.flux_net
-def sw_flux_up(s): return s.sws.flux.flux_up
-def sw_flux_dn(s): return s.sws.flux.flux_dn
-def sw_flux_net(s): return s.sws.flux.flux_net
-def sw_direct_flux_dn(s): return s.sws.flux.flux_dn_dir
-def net_flux(s): return s.net_flux_buffer
+def _domain_view(s, x):
+    """_domain_view (src/api/getters.jl:40-47): every getter with a vertical dimension returns a VIEW of the solver's
+    buffer without the extra isothermal boundary layer / level (`view(x, 1:size(x, 1) - Int(bl), :)`), the whole array
+    when there is none.  numpy arrays are in the reference's index order (vertical first); device tensors carry the
+    reversed shape (vertical last)."""
+    if x is None:
+        return None
+    bl = int(bool(s.isothermal_boundary_layer))
+    if isinstance(x, np.ndarray):
+        return x[:x.shape[0] - bl]
+    return x[..., :x.shape[-1] - bl]
+
+
+def lw_flux_up(s): return _domain_view(s, s.lws.flux.flux_up)
+def lw_flux_dn(s): return _domain_view(s, s.lws.flux.flux_dn)
+def lw_flux_net(s): return _domain_view(s, s.lws.flux.flux_net)
+def sw_flux_up(s): return _domain_view(s, s.sws.flux.flux_up)
+def sw_flux_dn(s): return _domain_view(s, s.sws.flux.flux_dn)
+def sw_flux_net(s): return _domain_view(s, s.sws.flux.flux_net)
+def sw_direct_flux_dn(s): return _domain_view(s, s.sws.flux.flux_dn_dir)
+def net_flux(s): return _domain_view(s, s.net_flux_buffer)
 
 
 def _solver_band_flux(ws):   # getters.jl:398-404
@@ -213,34 +226,35 @@ def _solver_band_flux(ws):   # getters.jl:398-404
     return ws.band_flux
 
 
-def spectral_lw_flux_up(s): return _solver_band_flux(s.lws).flux_up
-def spectral_lw_flux_dn(s): return _solver_band_flux(s.lws).flux_dn
-def spectral_lw_flux_net(s): return _solver_band_flux(s.lws).flux_net
-def spectral_sw_flux_up(s): return _solver_band_flux(s.sws).flux_up
-def spectral_sw_flux_dn(s): return _solver_band_flux(s.sws).flux_dn
-def spectral_sw_flux_net(s): return _solver_band_flux(s.sws).flux_net
+def spectral_lw_flux_up(s): return _domain_view(s, _solver_band_flux(s.lws).flux_up)
+def spectral_lw_flux_dn(s): return _domain_view(s, _solver_band_flux(s.lws).flux_dn)
+def spectral_lw_flux_net(s): return _domain_view(s, _solver_band_flux(s.lws).flux_net)
+def spectral_sw_flux_up(s): return _domain_view(s, _solver_band_flux(s.sws).flux_up)
+def spectral_sw_flux_dn(s): return _domain_view(s, _solver_band_flux(s.sws).flux_dn)
+def spectral_sw_flux_net(s): return _domain_view(s, _solver_band_flux(s.sws).flux_net)
 def lw_band_bounds(s): return s.lookups.lookup_lw.bnd_lims_wn
 def sw_band_bounds(s): return s.lookups.lookup_sw.bnd_lims_wn
-def clear_lw_flux_up(s): return s.clear_flux_lw.flux_up
-def clear_lw_flux_dn(s): return s.clear_flux_lw.flux_dn
-def clear_lw_flux_net(s): return s.clear_flux_lw.flux_net
-def clear_sw_flux_up(s): return s.clear_flux_sw.flux_up
-def clear_sw_flux_dn(s): return s.clear_flux_sw.flux_dn
-def clear_sw_direct_flux_dn(s): return s.clear_flux_sw.flux_dn_dir
-def clear_sw_flux_net(s): return s.clear_flux_sw.flux_net
-def clear_net_flux(s): return s.clear_net_flux_buffer
+def clear_lw_flux_up(s): return _domain_view(s, s.clear_flux_lw.flux_up)
+def clear_lw_flux_dn(s): return _domain_view(s, s.clear_flux_lw.flux_dn)
+def clear_lw_flux_net(s): return _domain_view(s, s.clear_flux_lw.flux_net)
+def clear_sw_flux_up(s): return _domain_view(s, s.clear_flux_sw.flux_up)
+def clear_sw_flux_dn(s): return _domain_view(s, s.clear_flux_sw.flux_dn)
+def clear_sw_direct_flux_dn(s): return _domain_view(s, s.clear_flux_sw.flux_dn_dir)
+def clear_sw_flux_net(s): return _domain_view(s, s.clear_flux_sw.flux_net)
+def clear_net_flux(s): return _domain_view(s, s.clear_net_flux_buffer)
 def lw_cloud_cover(s): return s.as_.cloud_state.cld_cover_lw
 def sw_cloud_cover(s): return s.as_.cloud_state.cld_cover_sw
 def aod_sw_extinction(s): return s.as_.aerosol_state.aod_sw_ext
 def aod_sw_scattering(s): return s.as_.aerosol_state.aod_sw_sca
-def level_pressure(s): return s.as_.p_lev
-def layer_pressure(s): return s.as_.p_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[1]
-def layer_temperature(s): return s.as_.t_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[2]
-def level_temperature(s): return s.as_.t_lev
+def level_pressure(s): return _domain_view(s, s.as_.p_lev)
+def layer_pressure(s): return _domain_view(s, s.as_.p_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[1])
+def layer_temperature(s): return _domain_view(s, s.as_.t_lay if isinstance(s.as_, GrayAtmosphericState) else s.as_.layerdata[2])
+def level_temperature(s): return _domain_view(s, s.as_.t_lev)
 def surface_temperature(s): return s.as_.t_sfc
 
 
 def heating_rate(s: RRTMGPSolver):
-    """heating_rate (src/api/standalone.jl:100-122): (g / cp) dF_net/dp per layer [K/s]; fresh array."""
-    nf, p = np.asfortranarray(net_flux(s)), np.asfortranarray(to_host(level_pressure(s)))
-    return rte.compute_gray_heating_rate(s.lws.ws, p, nf, s.params.cp_d, s.params.grav)
+    """heating_rate (src/api/standalone.jl:100-122): (g / cp) dF_net/dp per layer [K/s]; fresh array.  Like the reference it
+    hands `level_pressure(s)` and `net_flux(s)` — domain VIEWS — and the domain layer count to the device method; nothing
+    is copied on the way (rrtmgp_view2d)."""
+    return rte.compute_gray_heating_rate(s.lws.ws, level_pressure(s), net_flux(s), s.params.cp_d, s.params.grav)

@@ -163,3 +163,28 @@ def test_malformed_views_are_refused():
     assert L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 8, 12, None, C.byref(view(out)), C.byref(pd), None, None) != 0
     assert L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 0, 12, C.byref(view(p_lev)), C.byref(view(out)), C.byref(pd),
                                         None, None) != 0
+
+
+def test_solver_getters_are_domain_views_and_heating_rate_uses_them(tables64):
+    """Layer 2 with an isothermal boundary layer (solver.jl:136-331): the solver's arrays carry one extra layer / level on
+    top, every getter with a vertical dimension returns a VIEW without it (getters.jl:40-47) and `heating_rate` hands those
+    views and the domain layer count to compute_gray_heating_rate! (standalone.jl:106-122) — one layer fewer than the
+    workspace, uncopied."""
+    from rrtmgp_jl_amd import solver as L2
+    from rrtmgp_jl_amd.states import TEST_PARAMETERS
+    t = tables64
+    ncol, nlay = 7, 21                        # 20 domain layers + the boundary layer
+    as_, lb, sb = S.make_columns(ncol, nlay, np.float64, seed=23, night_fraction=0.2)
+    lookups = L2.LookupBundle(t["lw"], t["sw"], t["cld_lw"], t["cld_sw"])
+    s = L2.RRTMGPSolver(L2.AllSkyRadiation(reset_rng_seed=True), TEST_PARAMETERS, lb, sb, as_, lookups=lookups,
+                        isothermal_boundary_layer=True)
+    L2.update_fluxes(s, 7)
+    nf, p = L2.net_flux(s), L2.level_pressure(s)
+    assert nf.shape == (nlay, ncol) and p.shape == (nlay, ncol)               # nlev - 1 levels
+    assert np.shares_memory(nf, s.net_flux_buffer) and np.shares_memory(p, as_.p_lev)
+    assert L2.lw_flux_up(s).shape == (nlay, ncol) and L2.layer_temperature(s).shape == (nlay - 1, ncol)
+    assert not nf.flags.f_contiguous                                          # a strided view: column stride nlev
+    hr = L2.heating_rate(s)
+    assert hr.shape == (nlay - 1, ncol)
+    np.testing.assert_allclose(hr, TEST_PARAMETERS.grav * (nf[1:] - nf[:-1]) / (p[1:] - p[:-1]) / TEST_PARAMETERS.cp_d,
+                               rtol=1e-12)
