@@ -358,3 +358,56 @@ def test_allocation_lint_fails_on_the_round2_file():
     assert "call of `get!`" in by_fn.get("workspace", ()) and "closure" in by_fn.get("workspace", ()), by_fn.get("workspace")
     assert "call of `get!`" in by_fn.get("lookup_handle", ()), by_fn.get("lookup_handle")
     assert len(found) >= 20, len(found)
+
+
+# ---- ccall argument TYPES against the C prototypes -------------------------------------------------------------------
+_C2JL = {
+    "int": {"Cint"}, "int32_t": {"Int32", "Cint"}, "int64_t": {"Int64"}, "uint64_t": {"UInt64"}, "double": {"Float64"},
+    "size_t": {"Csize_t"}, "char*": {"Ptr{UInt8}"}, "constint32_t*": {"Ptr{Int32}"},
+    "void*": {"P", "Ptr{Cvoid}"}, "constvoid*": {"P", "Ptr{Cvoid}"},
+    "rrtmgp_workspace*": {"P", "Ptr{Cvoid}"}, "constrrtmgp_workspace*": {"P", "Ptr{Cvoid}"},
+    "rrtmgp_lookup*": {"P", "Ptr{Cvoid}"}, "constrrtmgp_lookup*": {"P", "Ptr{Cvoid}"},
+    "rrtmgp_lookup**": {"Ref{Ptr{Cvoid}}"}, "rrtmgp_workspace**": {"Ref{Ptr{Cvoid}}"},
+}
+_STRUCT2JL = {"rrtmgp_gas_lookup_desc": "GasLookupDesc", "rrtmgp_cloud_lookup_desc": "CloudLookupDesc",
+              "rrtmgp_aerosol_lookup_desc": "AerosolLookupDesc", "rrtmgp_atmos_state": "AtmosStateDesc",
+              "rrtmgp_lw_bcs": "LwBcsDesc", "rrtmgp_sw_bcs": "SwBcsDesc", "rrtmgp_flux_out": "FluxOutDesc",
+              "rrtmgp_solve_opts": "SolveOpts", "rrtmgp_gray_state": "GrayStateDesc", "rrtmgp_params": "ParamsDesc",
+              "rrtmgp_prepare_opts": "PrepareOpts", "rrtmgp_view2d": "View2D"}
+
+
+def test_ccall_argument_types_match_the_header():
+    """Argument by argument: an `int64_t` extent must be passed as Int64 (not Int32 / Cint), a `const rrtmgp_view2d *` as
+    Ref{View2D}, handles as pointers, the return type as Cint (or Cstring / Cdouble where the header says so).  Catches the
+    class of ABI bug a count check cannot: a 32-bit integer in a 64-bit slot."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rrtmgp_hip.h")).read(), flags=re.S)
+    toks = [t for t in JLITE.tokenize(JL) if t.kind != "nl"]
+    n_checked = 0
+    for i, t in enumerate(toks):
+        if not (t.kind == "id" and t.text == "ccall" and toks[i + 1].text == "("):
+            continue
+        close = JLITE._matching(toks, i + 1)
+        args = JLITE._split_top(toks[i + 2:close], ",")
+        sym = args[0][1].text.lstrip(":")
+        ret = "".join(x.text for x in args[1])
+        types = ["".join(x.text for x in a) for a in JLITE._split_top(args[2][1:-1], ",")]
+        proto = re.search(r"([\w \*]+?)\b%s\s*\(([^;]*?)\)\s*;" % sym, header, flags=re.S)
+        assert proto, sym
+        c_ret = proto.group(1).split()[-1] if proto.group(1).split() else "int"
+        assert ret == {"int": "Cint", "double": "Cdouble"}.get(c_ret, ret), (sym, ret, c_ret)
+        c_args = [a.strip() for a in proto.group(2).split(",") if a.strip() and a.strip() != "void"]
+        assert len(c_args) == len(types), sym
+        for k, (ca, jt) in enumerate(zip(c_args, types)):
+            words = ca.replace("*", " * ").split()
+            if words[-1] != "*" and not words[-1].endswith("_t") and words[-1] not in ("int", "double", "size_t"):
+                words = words[:-1]                       # drop the parameter name
+            ctype = "".join(words)
+            base = ctype.replace("const", "").rstrip("*")
+            if base in _STRUCT2JL and ctype.endswith("*") and not ctype.endswith("**"):
+                allowed = {"Ref{%s}" % _STRUCT2JL[base]}
+            else:
+                allowed = _C2JL.get(ctype)
+            assert allowed is not None, (sym, k, ca, ctype)
+            assert jt in allowed, f"{sym}: argument {k + 1} is `{ca}` in the header but `{jt}` in the ccall (allowed: {sorted(allowed)})"
+            n_checked += 1
+    assert n_checked >= 100, n_checked
