@@ -411,3 +411,34 @@ def test_ccall_argument_types_match_the_header():
             assert jt in allowed, f"{sym}: argument {k + 1} is `{ca}` in the header but `{jt}` in the ccall (allowed: {sorted(allowed)})"
             n_checked += 1
     assert n_checked >= 100, n_checked
+
+
+def test_every_array_owner_used_in_a_ccall_is_gc_preserved():
+    """`ptr(x)` / `pointer(x)` hand raw addresses to C: the object they came from must be rooted for the duration of the
+    call (`GC.@preserve`).  For every device method, every parameter that carries arrays (by its annotation) and is named
+    inside the ccall's argument list must also be named in the `GC.@preserve` that wraps that ccall."""
+    carriers = ("AbstractArray", "AtmosphericState", "GrayAtmosphericState", "LwBCs", "SwBCs", "FluxLW", "FluxSW")
+    mod = _module()
+    n = 0
+    for ms in _device_methods(mod).values():
+        for m in ms:
+            toks = [t for t in m.body if t.kind != "nl"]
+            idx = [i for i, t in enumerate(toks) if t.kind == "id" and t.text == "ccall"]
+            if not idx:
+                continue
+            params = {p.name: p.type for p in m.params if p.name}
+            # untyped parameters of the gray heating-rate method are arrays too (reference signature has no annotations)
+            arrays = {nm for nm, ty in params.items() if any(c in ty for c in carriers)}
+            if m.name.split(".")[-1] == "compute_gray_heating_rate!":
+                arrays |= {"hr_lay", "p_lev", "flux_net"}
+            for i in idx:
+                close = JLITE._matching(toks, i + 1)
+                used = {t.text for t in toks[i + 2:close] if t.kind == "id"} & arrays
+                # the @preserve list: identifiers between the macro and the `check(` that wraps the ccall
+                j = max(k for k in range(i) if toks[k].kind == "macro" and toks[k].text.endswith("@preserve"))
+                k = next(q for q in range(j + 1, i) if toks[q].text == "check")
+                preserved = {t.text for t in toks[j + 1:k] if t.kind == "id"}
+                missing = used - preserved
+                assert not missing, (m.name, sorted(missing), sorted(preserved))
+                n += len(used)
+    assert n >= 30, n
