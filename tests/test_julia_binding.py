@@ -442,3 +442,64 @@ def test_every_array_owner_used_in_a_ccall_is_gc_preserved():
                 assert not missing, (m.name, sorted(missing), sorted(preserved))
                 n += len(used)
     assert n >= 30, n
+
+
+def test_descriptor_constructors_pass_one_value_per_field():
+    """The C-struct mirrors are built with positional constructors: `AtmosStateDesc(0, kind, ncol, ...)`.  One argument too
+    few or too many is a MethodError at the first solve; a splatted tuple (`band_ptrs(band)...`) counts as the length of
+    the tuple its methods return."""
+    toks = [t for t in JLITE.tokenize(JL) if t.kind != "nl"]
+    mod = _module()
+    tuple_len = {}
+    for m in mod.methods:       # short methods returning a tuple literal: name -> its length (all methods must agree)
+        body = [t for t in m.body if t.kind != "nl"]
+        if body and body[0].text == "(" and JLITE._matching(body, 0) == len(body) - 1:
+            n = len(JLITE._split_top(body[1:-1], ","))
+            tuple_len.setdefault(m.name, set()).add(n)
+    assert tuple_len.get("band_ptrs") == {4}, tuple_len.get("band_ptrs")
+    n_calls = 0
+    for i, t in enumerate(toks):
+        if t.kind == "id" and t.text in PAIRS and i + 1 < len(toks) and toks[i + 1].text == "(" and toks[i - 1].text not in ("struct", "{", "::"):
+            close = JLITE._matching(toks, i + 1)
+            args = JLITE._split_top(toks[i + 2:close], ",")
+            n = 0
+            for a in args:
+                if a and a[-1].text == "..." and a[0].kind == "id" and a[0].text in tuple_len:
+                    (k,) = tuple_len[a[0].text]
+                    n += k
+                else:
+                    n += 1
+            want = len(julia_fields(t.text))
+            assert n == want, f"{t.text}(...) at line {t.line}: {n} arguments for {want} fields"
+            n_calls += 1
+    assert n_calls >= 20, n_calls
+
+
+def test_descriptor_arguments_are_not_transposed():
+    """Positional constructors again: when an argument is `ptr(x.name)` (or `flux_ptr(f.name)`, `pointer(l.name)`) and
+    `name` is also the name of a field of the C struct, it must sit at THAT field's position — `ptr(as.t_lev)` in the
+    `p_lev` slot compiles and runs, and gives wrong fluxes."""
+    toks = [t for t in JLITE.tokenize(JL) if t.kind != "nl"]
+    checked = 0
+    for i, t in enumerate(toks):
+        if not (t.kind == "id" and t.text in PAIRS and toks[i + 1].text == "(" and toks[i - 1].text not in ("struct", "{", "::")):
+            continue
+        names = [f for f, _ in julia_fields(t.text)]
+        close = JLITE._matching(toks, i + 1)
+        pos = 0
+        for a in JLITE._split_top(toks[i + 2:close], ","):
+            if a and a[-1].text == "...":
+                pos += 4            # band_ptrs(band)... (checked by the arity test)
+                continue
+            # the last `.field` inside the argument, ignoring ternaries' C_NULL branches
+            fields = []
+            for k in range(len(a) - 1):
+                if a[k].kind == "id" and a[k].text in ("ptr", "pointer", "flux_ptr") and a[k + 1].text == "(":
+                    inner = a[k + 2:JLITE._matching(a, k + 1)]
+                    fields += [inner[q + 1].text for q in range(len(inner) - 1) if inner[q].text == "." and inner[q + 1].kind == "id"][-1:]
+            if fields and fields[-1] in names:
+                assert names[pos] == fields[-1], (f"{t.text}(...) line {t.line}: argument {pos + 1} reads `.{fields[-1]}` "
+                                                   f"but fills the field `{names[pos]}`")
+                checked += 1
+            pos += 1
+    assert checked >= 45, checked
