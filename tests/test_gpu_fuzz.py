@@ -23,19 +23,28 @@ def _maxdiff(a, b, names):
     return max(float(np.abs(np.float64(getattr(a, n)) - np.float64(getattr(b, n))).max()) for n in names)
 
 
-def _budget(FT, lw: bool, max_flux: float) -> float:
+def _budget(FT, lw: bool, max_flux: float, particles: bool = False) -> float:
     """Float64: the summation order over g-points and the regrouped interpolations differ from the oracle's by rounding,
     and the recurrences carry that through the column: a RELATIVE budget plus 1e-9 W/m2.  LW (and every no-scattering
-    solver): 1e-11 of the largest flux (observed over 500 random cases: 5e-15).  SW two-stream: 3e-11 — this kernel closes
+    solver): 1e-11 of the largest flux (observed over 1500 random cases: 5e-15).  SW two-stream: 3e-11 — this kernel closes
     the adding relations from the top of the atmosphere while the oracle (like the reference) adds from the surface up
     (DESIGN.md section 5, item 5); the two are algebraically identical but amplify rounding by different condition numbers
     where layers scatter almost conservatively, and in deep aerosol-laden columns that shows: seed 204 (129 layers, MERRA
-    aerosols, no clouds) differs by 1.9e-8 on 1.49e3 W/m2 = 1.25e-11, the largest of 500 cases (all others < 3e-13).
-    Float32 (HIP-F32 against the oracle in Float32 on the same inputs and McICA sample): the reference's own F32
-    ratchet, test/float32_consistency.jl:53-62 — LW 1e-3, SW 3e-2 W/m2 (observed: 5.7e-4 / 6.7e-3)."""
+    aerosols, no clouds) differs by 1.9e-8 on 1.49e3 W/m2 = 1.25e-11, the largest of 1500 cases (99.9 % < 5e-12).
+
+    Float32: HIP-F32 is compared with the oracle in Float32 on the same inputs (same McICA sample), i.e. two Float32
+    evaluations with different operation orders.  The reference bounds |Float32 - Float64| by its ratchet
+    (test/float32_consistency.jl:53-62): LW 1e-3, SW 3e-2 clear / 1.2e-1 cloudy.  LW: 1e-3 holds directly (observed
+    5.8e-4).  SW, gas only: 3e-2 (observed 2.0e-3).  SW with clouds or aerosols (near-conservative scattering is
+    ill-conditioned in Float32): each side may use the 1.2e-1 of the ratchet, so two Float32 results may differ by 2.4e-1;
+    observed over 1500 cases: 1.26e-1 (seed 633), where tools/f32_fuzz_diagnose.py measures |HIP-F32 - F64| = 9.4e-2 and
+    |oracle-F32 - F64| = 4.2e-2 on the promoted inputs — both inside the reference's 1.2e-1; 99.9 % of the comparisons are
+    below 5.6e-2."""
     if FT is np.float64:
         return (1e-11 if lw else 3e-11) * max_flux + 1e-9
-    return 1e-3 if lw else 3e-2
+    if lw:
+        return 1e-3
+    return 2.4e-1 if particles else 3e-2
 
 
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
@@ -87,7 +96,8 @@ def _random_configuration(seed, FT):
         lw_ = len(names) == 3 and what.startswith("lw")
         d = max(float(np.abs(np.float64(getattr(got, n)) - np.float64(getattr(ref, n))).max()) for n in names)
         mx = max(float(np.abs(np.float64(getattr(ref, n))).max()) for n in names)
-        tol = _budget(FT, lw_, mx)
+        # scattering particles in THIS flux set: aerosols, or clouds unless it is the clear-sky twin; never in no-scattering solves
+        tol = _budget(FT, lw_, mx, particles=(aerosols or (clouds and "clear" not in what)) and "noscat" not in what)
         if _REPORT:
             with open(_REPORT, "a") as fh:
                 fh.write(f"{np.dtype(FT).name} {what} {d:.3e} {mx:.3e} {tol:.3e} | {tag}\n")
