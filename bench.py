@@ -119,6 +119,19 @@ def run_leg(name, extra, env=None, timeout=600):
         return {"error": repr(ex)[:300]}
 
 
+def self_launch(n):
+    """Re-executes this command line under torch.distributed.run with `n` ranks on 127.0.0.1 (a free port)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this platform
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
     import torch
@@ -134,8 +147,12 @@ def main():
             raise SystemExit("--single-process is one process: do not launch it through torch.distributed.run")
         args.host, args.shards = True, args.gpus
     elif args.gpus != world:
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # a bare `python bench.py --gpus N`: start the N ranks ourselves (what the driver's torch.distributed.run
+            # command does), forward the one JSON line of rank 0 and its exit status
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+                         f"--nproc-per-node {args.gpus} (a bare `python bench.py --gpus N` starts its own ranks)")
     _lib.require_gpu()
     # RRTMGP_BENCH_BACKEND=gloo + RRTMGP_BENCH_SHARE_GPU=1 is a test hook: several ranks on ONE GPU, to exercise the
     # multi-process path (barrier, MAX over ranks, rank-0 report) where only one device exists.  Never for numbers.
@@ -248,8 +265,16 @@ def main():
                 host_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks_seen, rank_ms, rank_ncol = 1, [1e3 * elapsed / args.steps], [ncol]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cdev = dev if backend == "nccl" else "cpu"
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([elapsed, float(ncol)], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(every, mine)     # per-rank wall time of the timed region and columns per step
+        rank_ms = [1e3 * float(e[0].item()) / args.steps for e in every]
+        rank_ncol = [int(e[1].item()) for e in every]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     per_step = [a.elapsed_time(b) for a, b in ev] if ev else host_ms
@@ -284,10 +309,13 @@ def main():
         if args.leg:   # child-process mode: a compact record for the parent's JSON line
             rec = {"value": value, "unit": "columns/s", "ms_per_step": 1e3 * elapsed / args.steps,
                    "lw_kernel_ms": k_lw, "sw_kernel_ms": k_sw, "ncol": ncol, "dtype": args.dtype,
-                   "library": os.path.basename(_lib.SO_PATH),
-                   "valu": {"achieved": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12, "peak": valu_peak, "unit": "TFLOP/s",
-                            "frac": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12 / valu_peak,
-                            "algorithmic_flops_per_column": flops_col}}
+                   "library": os.path.basename(_lib.SO_PATH)}
+            if not args.host:   # (a pipelined host solve is many chunk launches: the library's kernel timer holds the last one only)
+                rec["valu"] = {"achieved": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12, "peak": valu_peak, "unit": "TFLOP/s",
+                               "frac": flops_col * ncol / ((k_lw + k_sw) * 1e-3) / 1e12 / valu_peak,
+                               "algorithmic_flops_per_column": flops_col}
+            else:
+                rec.pop("lw_kernel_ms"), rec.pop("sw_kernel_ms")
             if noscat or not clouds or args.lw_only:
                 rec["workload"] = (f"{'NoScatLWRTE x ' + str(args.angles) + ' angle(s)' if noscat else 'TwoStreamLWRTE'}"
                                    f"{'' if args.lw_only else ' + TwoStreamSWRTE'}, {'McICA clouds' if clouds else 'clear sky'}, "
@@ -355,6 +383,9 @@ def main():
                                        "(rrtmgp_hip_workspace_create_multi), no collective" if single else
                                        f"columns sharded over {world} GPU(s), no collective")},
             "step_ms": step_ms,
+            # what the process group reported after init_process_group, every rank's own wall time per step (the job's
+            # ms_per_step is their MAX) and the columns each rank solved per step
+            "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms, "rank_columns": rank_ncol,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_column": dom_bytes, "kernel_ms": dom_ms,
@@ -412,6 +443,11 @@ def main():
             out["cpu_baseline"] = {"value": n / tc, "unit": "columns/s", "cores": min(O.n_threads(), 32), "kind": "port",
                                    "sample": f"{n} columns of the same workload, oracle/rrtmgp_oracle.c "
                                              f"(gcc -O2, OpenMP over columns), {tc:.1f} s"}
+        if args.host:
+            # a pipelined / sharded host solve is many launches: the library's kernel timer holds the last chunk only, so
+            # per-kernel rates would be fractions of nothing
+            for key in ("roofline", "valu", "kernels"):
+                out[key] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -113,6 +113,55 @@ def test_bench_multi_process_path_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_bare_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO WORLD_SIZE in the environment (how the driver starts the N = 1 run): the
+    script launches its own two ranks under torch.distributed.run on 127.0.0.1 and rank 0 prints the one JSON line, with
+    the world size the process group reported and every rank's own time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RRTMGP_BENCH_BACKEND="gloo", RRTMGP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--ncol", "4096", "--cpu-sample", "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and len(d["rank_ms_per_step"]) == 2 and d["rank_columns"] == [4096, 4096]
+    assert max(d["rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-9)
+    assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """The re-exec of a bare `--gpus N` command: torch.distributed.run, one node, N ranks, loopback rendezvous, the
+    original arguments unchanged (no GPU needed: the child process is not started)."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.gpu
 def test_bench_single_process_fan_out_on_one_gpu():
     """`bench.py --gpus 2 --single-process`: ONE process, host arrays of 2 x ncol columns, the library's multi-device
     workspace fans out (device ids wrap onto the only GPU of the test box).  What a Julia host gets from
