@@ -430,6 +430,60 @@ int rrtmgp_hip_compute_gray_heating_rate(rrtmgp_workspace *ws, int32_t mem, int6
                                          const rrtmgp_view2d *hr_lay, const rrtmgp_view2d *p_lev,
                                          const rrtmgp_view2d *flux_net, double cp_d, double grav);
 
+/* ---- the whole radiation step (Layer 2): update_fluxes!(s::RRTMGPSolver) ---------------------------------------
+ *
+ * update_fluxes!(s, seedval)  src/api/update_fluxes.jl:223-233 =
+ *     prepare_atmosphere!(s) (:252-281) -> update_lw_fluxes!(s) (:12-65) -> update_sw_fluxes!(s) (:74-128)
+ *     -> update_net_fluxes!(s) (:165-194),
+ * for the spectral radiation methods (ClearSkyRadiation, AllSkyRadiation, AllSkyRadiationWithClearSkyDiagnostics), in ONE
+ * call: the caller's state crosses to the device once (the reference's extension path stages it for every solve: LW, SW,
+ * twice each with diagnostics, plus in and out for compute_col_gas!), then on the workspace stream
+ *     [prepare kernel]  ->  LW solve  ->  SW solve  ->  net = lw_net + sw_net,
+ * and what comes back is the fluxes, the diagnostics, and — only when `prepare` is given — the prepared state arrays
+ * (layerdata, p_lev, t_lev, vmr_h2o or the full vmr; the cloud / aerosol inputs and vmr_o3 as well when the isothermal
+ * boundary layer is filled).  Large host-array steps run as a pipeline of column chunks (uploads of chunk c + 1 and
+ * downloads of chunk c - 1 overlap the kernels of chunk c); multi-device workspaces shard the columns; device arrays are
+ * used in place.  The bits are those of the separate calls.
+ *
+ *  - `flux_lw` / `flux_sw` are what the step leaves for the getters: a Julia host passes the arrays of
+ *    `s.presented_flux_lw` / `_sw` (FluxPresentation, (nlev, ncol): RRTMGP_LAYOUT_NLEV_NCOL), which makes the
+ *    update_presentation! copies (update_fluxes.jl:15,77) unnecessary.  Their `clear_flux_*` slots take the arrays of
+ *    `s.clear_flux_lw` / `_sw` (AllSkyRadiationWithClearSkyDiagnostics): two-stream solvers fill them in the same launch
+ *    as the all-sky fluxes (the reference solves twice, :39-65, :101-128); a no-scattering LW solver, or a step that also
+ *    keeps per-band fluxes, runs the cloudless solve first on the staged state, as the reference does.
+ *  - `net_flux` = flux_lw.flux_net + flux_sw.flux_net and `clear_net_flux` = the clear-sky pair, both FT (nlev, ncol)
+ *    whatever the layout of the flux arrays (transpose_sum_into!, src/optics/Fluxes.jl:407-424); either may be NULL.
+ *    `mem` of these two arrays is `flux_lw->mem`.
+ *  - `lookup_*_cld` NULL = no clouds (ClearSkyRadiation); `lookup_*_aero` NULL = `aerosol_radiation = false`.
+ *  - `prepare` NULL = the state is already prepared (no kernel, nothing of the state is copied back).
+ *  - `opts->seed` keys the McICA streams of both solves (LW and SW draw from separate streams, `is_sw`);
+ *    `opts->n_gauss_angles` applies to a no-scattering LW solver; `opts->metric_scaling` = deep_atmosphere_inverse_scaling. */
+#define RRTMGP_LW_TWOSTREAM 1 /* TwoStreamLWRTE */
+#define RRTMGP_LW_NOSCAT 0    /* NoScatLWRTE */
+typedef struct rrtmgp_update_fluxes_args {
+    const rrtmgp_lookup *lookup_lw, *lookup_sw;         /* s.lookups.lookup_lw / lookup_sw */
+    const rrtmgp_lookup *lookup_lw_cld, *lookup_sw_cld; /* or NULL */
+    const rrtmgp_lookup *lookup_lw_aero, *lookup_sw_aero; /* or NULL */
+    const rrtmgp_atmos_state *as;   /* s.as */
+    const rrtmgp_lw_bcs *bcs_lw;    /* s.lws.bcs */
+    const rrtmgp_sw_bcs *bcs_sw;    /* s.sws.bcs */
+    const rrtmgp_flux_out *flux_lw; /* flux_dn_dir NULL */
+    const rrtmgp_flux_out *flux_sw;
+    void *net_flux;                 /* FT (nlev, ncol) or NULL: s.net_flux_buffer */
+    void *clear_net_flux;           /* FT (nlev, ncol) or NULL: s.clear_net_flux_buffer */
+    const rrtmgp_params *params;    /* needed with `prepare` */
+    const rrtmgp_prepare_opts *prepare; /* or NULL */
+    const rrtmgp_solve_opts *opts;  /* or NULL */
+    int32_t lw_solver;              /* RRTMGP_LW_TWOSTREAM / RRTMGP_LW_NOSCAT; the SW solver is two-stream (solver.jl:176-182) */
+    int32_t _pad;
+} rrtmgp_update_fluxes_args;
+
+int rrtmgp_hip_update_fluxes(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_args *args);
+
+/* Bytes this workspace (all shards) has moved host -> device and device -> host since it was created: what a host-array
+ * call costs on PCIe (bench.py reports bytes per column of the Layer-2 step; tests count the staging of strided views). */
+int rrtmgp_hip_workspace_transfer_bytes(const rrtmgp_workspace *ws, uint64_t *h2d, uint64_t *d2h);
+
 /* ---- several GPUs from ONE host process (SURVEY.md §8(b) "Threading", §8(e)) ---------------
  *
  * The reference shards columns over devices above its API (one ClimaComms context per rank);
@@ -521,7 +575,7 @@ const char *rrtmgp_hip_version(void);
 const char *rrtmgp_hip_build_flags(void);
 /* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,
  * 1 gas_lookup_desc, 2 cloud_lookup_desc, 3 aerosol_lookup_desc, 4 atmos_state, 5 lw_bcs,
- * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d); -1 otherwise.  Lets a
+ * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d, 13 update_fluxes_args); -1 otherwise.  Lets a
  * foreign-language binding verify its struct mirror at load time. */
 int rrtmgp_hip_abi_sizeof(int which);
 

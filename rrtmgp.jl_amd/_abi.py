@@ -99,6 +99,16 @@ class View2D(C.Structure):
     _fields_ = [("ptr", vp), ("stride0", i64), ("stride1", i64)]
 
 
+class UpdateFluxesArgs(C.Structure):
+    """rrtmgp_update_fluxes_args: the whole radiation step (update_fluxes!, src/api/update_fluxes.jl:223-233)."""
+    _fields_ = [("lookup_lw", vp), ("lookup_sw", vp), ("lookup_lw_cld", vp), ("lookup_sw_cld", vp), ("lookup_lw_aero", vp),
+                ("lookup_sw_aero", vp), ("as_", C.POINTER(AtmosState)), ("bcs_lw", C.POINTER(LwBcs)), ("bcs_sw", C.POINTER(SwBcs)),
+                ("flux_lw", C.POINTER(FluxOut)), ("flux_sw", C.POINTER(FluxOut)), ("net_flux", vp), ("clear_net_flux", vp),
+                ("params", C.POINTER(Params)), ("prepare", C.POINTER(PrepareOpts)), ("opts", C.POINTER(SolveOpts)),
+                ("lw_solver", i32), ("_pad", i32)]
+
+
+LW_TWOSTREAM, LW_NOSCAT = 1, 0
 PREP_INTERPOLATE, PREP_ISOTHERMAL, PREP_CLIP, PREP_COL_DRY, PREP_ALL = 1, 2, 4, 8, 15
 PREP_REL_HUM = 16   # optional extra step: relative humidity refreshed in the same launch
 INTERP = {"none": 0, "arithmetic_mean": 1, "geometric_mean": 2, "uniform_z": 3, "uniform_p": 4, "best_fit": 5}

@@ -518,8 +518,14 @@ static int select_device(int device) {
 enum Slot {
     S_LAYERDATA = 0, S_TLEV, S_TSFC, S_VMR_H2O, S_VMR_O3, S_VMR, S_CLD_RL, S_CLD_RI, S_CLD_PL, S_CLD_PI, S_CLD_F,
     S_CLD_COVER, S_AERO_SIZE, S_AERO_MASS, S_AOD_EXT, S_AOD_SCA, S_BC0, S_BC1, S_BC2, S_BC3, S_FLUX_UP, S_FLUX_DN,
-    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_CLR_UP, S_CLR_DN, S_CLR_NET, S_CLR_DIR, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_ZC, S_ZF, S_NSLOTS
+    S_FLUX_NET, S_FLUX_DIR, S_BAND_UP, S_BAND_DN, S_BAND_NET, S_CLR_UP, S_CLR_DN, S_CLR_NET, S_CLR_DIR, S_METRIC, S_PLEV, S_LAT, S_TLAY, S_PLAY, S_AUX0, S_AUX1, S_ZC, S_ZF,
+    // the whole-step entry (rrtmgp_hip_update_fluxes) keeps the LW and the SW arrays of one step side by side: a second
+    // block of flux slots in the order of the first (S_FLUX_UP .. S_CLR_DIR), the LW boundary conditions, the second
+    // cloud cover and the two net-flux sums
+    S_X_FLUX_UP, S_X_FLUX_DN, S_X_FLUX_NET, S_X_FLUX_DIR, S_X_BAND_UP, S_X_BAND_DN, S_X_BAND_NET, S_X_CLR_UP, S_X_CLR_DN,
+    S_X_CLR_NET, S_X_CLR_DIR, S_LW_BC0, S_LW_BC1, S_CLD_COVER2, S_NET, S_CLR_NETSUM, S_NSLOTS
 };
+static_assert(S_X_CLR_DIR - S_X_FLUX_UP == S_CLR_DIR - S_FLUX_UP, "the second block of flux slots mirrors the first");
 
 struct Stager {
     rrtmgp_workspace *ws;
@@ -552,8 +558,15 @@ struct Stager {
     }
     // packed mode: the one upload, on the compute stream, right before the launch
     int flush() {
-        if (packed && in_hi) RR_HIP(hipMemcpyAsync(ws->bounce_d, ws->bounce_h, in_hi, hipMemcpyHostToDevice, ws->stream));
+        if (packed && in_hi) {
+            RR_HIP(hipMemcpyAsync(ws->bounce_d, ws->bounce_h, in_hi, hipMemcpyHostToDevice, ws->stream));
+            ws->h2d_bytes += in_hi;
+        }
         return RRTMGP_OK;
+    }
+    // read only, or (rw) read and written by the call: one upload either way, rw arrays also travel back
+    int io(bool rw, int mem, int slot, const void *p, size_t bytes, const void **out) {
+        return rw ? inout(mem, slot, p, bytes, (void **)out) : in(mem, slot, p, bytes, out);
     }
 
     // input: returns device pointer (copying H2D if mem == host)
@@ -570,7 +583,10 @@ struct Stager {
         }
         TRY(stage_ensure(ws, slot, bytes));
         host_range_check(ws, p, bytes);  // no stale page-lock registration under this buffer (host_pin)
-        if (!((keep >> slot) & 1)) RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
+        if (!((keep >> slot) & 1)) {
+            RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
+            ws->h2d_bytes += bytes;
+        }
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
     }
@@ -587,6 +603,7 @@ struct Stager {
         TRY(stage_ensure(ws, slot, width * height));
         host_range_check(ws, p, spitch * (height - 1) + width);
         RR_HIP(hipMemcpy2DAsync(ws->stage[slot].ptr, width, p, spitch, width, height, hipMemcpyHostToDevice, copy_stream()));
+        ws->h2d_bytes += width * height;
         *out = ws->stage[slot].ptr;
         return RRTMGP_OK;
     }
@@ -641,14 +658,17 @@ struct Stager {
         TRY(stage_ensure(ws, slot, bytes));
         host_range_check(ws, p, bytes);
         RR_HIP(hipMemcpyAsync(ws->stage[slot].ptr, p, bytes, hipMemcpyHostToDevice, copy_stream()));
+        ws->h2d_bytes += bytes;
         *outp = ws->stage[slot].ptr;
         backs.push_back({const_cast<void *>(p), ws->stage[slot].ptr, bytes});
         return RRTMGP_OK;
     }
     int finish() {
         if (packed) {
-            if (out_hi > out_lo)
+            if (out_hi > out_lo) {
                 RR_HIP(hipMemcpyAsync(ws->bounce_h + out_lo, ws->bounce_d + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, ws->stream));
+                ws->d2h_bytes += out_hi - out_lo;
+            }
             RR_HIP(hipStreamSynchronize(ws->stream));
             for (auto &b : backs) {
                 const char *src = ws->bounce_h + ((char *)b.dev - ws->bounce_d);
@@ -666,6 +686,7 @@ struct Stager {
         for (auto &b : backs) {
             if (!b.rows) RR_HIP(hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, s));
             else RR_HIP(hipMemcpy2DAsync(b.host, b.hpitch, b.dev, b.bytes, b.bytes, b.rows, hipMemcpyDeviceToHost, s));
+            ws->d2h_bytes += b.bytes * (b.rows ? b.rows : 1);
         }
         return RRTMGP_OK;
     }
@@ -677,25 +698,32 @@ struct Stager {
     }
 };
 
+// What a preparation step in the same call writes (rrtmgp_hip_update_fluxes with `prepare`): `core` = layerdata, t_lev,
+// vmr_h2o / the full vmr (interpolation, clipping, col_dry); `particles` = vmr_o3 and the cloud / aerosol inputs too (the
+// isothermal boundary layer fills their last layer).  Written arrays are staged in AND copied back.
+struct StateRW {
+    bool core = false, particles = false;
+};
 template <typename FT>
 static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, bool use_aero, bool lw, DevState<FT> &d,
-                       int64_t nrghice = 1) {
+                       int64_t nrghice = 1, StateRW rw = StateRW()) {
     const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1;
     RR_CHECK(as->layerdata && as->t_sfc && as->vmr, "atmospheric state: missing array");
     RR_CHECK(!lw || as->t_lev, "atmospheric state: t_lev is required for longwave");
     d.ncol = (int)ncol; d.nlay = (int)nlay; d.ngas = (int)as->ngas; d.vmr_kind = as->vmr_kind;
     const int mem = as->mem;
-    TRY(st.in(mem, S_LAYERDATA, as->layerdata, 4 * nlay * ncol * E, (const void **)&d.layerdata));
-    TRY(st.in(mem, S_TLEV, as->t_lev, nlev * ncol * E, (const void **)&d.t_lev));
+    TRY(st.io(rw.core, mem, S_LAYERDATA, as->layerdata, 4 * nlay * ncol * E, (const void **)&d.layerdata));
+    d.t_lev = nullptr;   // the shortwave kernels never read the level temperatures: not uploaded for them
+    if (lw) TRY(st.io(rw.core, mem, S_TLEV, as->t_lev, nlev * ncol * E, (const void **)&d.t_lev));
     TRY(st.in(mem, S_TSFC, as->t_sfc, ncol * E, (const void **)&d.t_sfc));
     if (as->vmr_kind == RRTMGP_VMR_GM) {
         RR_CHECK(as->vmr_h2o && as->vmr_o3, "VmrGM: vmr_h2o and vmr_o3 are required");
-        TRY(st.in(mem, S_VMR_H2O, as->vmr_h2o, nlay * ncol * E, (const void **)&d.vmr_h2o));
-        TRY(st.in(mem, S_VMR_O3, as->vmr_o3, nlay * ncol * E, (const void **)&d.vmr_o3));
+        TRY(st.io(rw.core, mem, S_VMR_H2O, as->vmr_h2o, nlay * ncol * E, (const void **)&d.vmr_h2o));
+        TRY(st.io(rw.particles, mem, S_VMR_O3, as->vmr_o3, nlay * ncol * E, (const void **)&d.vmr_o3));
         TRY(st.in(mem, S_VMR, as->vmr, as->ngas * E, (const void **)&d.vmr));
     } else {
         d.vmr_h2o = d.vmr_o3 = nullptr;
-        TRY(st.in(mem, S_VMR, as->vmr, (size_t)as->ngas * nlay * ncol * E, (const void **)&d.vmr));
+        TRY(st.io(rw.core, mem, S_VMR, as->vmr, (size_t)as->ngas * nlay * ncol * E, (const void **)&d.vmr));
     }
     d.cld_r_eff_liq = d.cld_r_eff_ice = d.cld_path_liq = d.cld_path_ice = d.cld_frac = nullptr;
     d.cld_cover = nullptr;
@@ -704,11 +732,11 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
         RR_CHECK(as->cld_frac && as->cld_r_eff_liq && as->cld_r_eff_ice && as->cld_path_liq && as->cld_path_ice,
                  "cloud lookup given but the state has no CloudState");
         RR_CHECK(as->ice_rgh >= 1 && as->ice_rgh <= nrghice, "ice_rgh must be in 1..nrghice of the cloud lookup");
-        TRY(st.in(mem, S_CLD_RL, as->cld_r_eff_liq, nlay * ncol * E, (const void **)&d.cld_r_eff_liq));
-        TRY(st.in(mem, S_CLD_RI, as->cld_r_eff_ice, nlay * ncol * E, (const void **)&d.cld_r_eff_ice));
-        TRY(st.in(mem, S_CLD_PL, as->cld_path_liq, nlay * ncol * E, (const void **)&d.cld_path_liq));
-        TRY(st.in(mem, S_CLD_PI, as->cld_path_ice, nlay * ncol * E, (const void **)&d.cld_path_ice));
-        TRY(st.in(mem, S_CLD_F, as->cld_frac, nlay * ncol * E, (const void **)&d.cld_frac));
+        TRY(st.io(rw.particles, mem, S_CLD_RL, as->cld_r_eff_liq, nlay * ncol * E, (const void **)&d.cld_r_eff_liq));
+        TRY(st.io(rw.particles, mem, S_CLD_RI, as->cld_r_eff_ice, nlay * ncol * E, (const void **)&d.cld_r_eff_ice));
+        TRY(st.io(rw.particles, mem, S_CLD_PL, as->cld_path_liq, nlay * ncol * E, (const void **)&d.cld_path_liq));
+        TRY(st.io(rw.particles, mem, S_CLD_PI, as->cld_path_ice, nlay * ncol * E, (const void **)&d.cld_path_ice));
+        TRY(st.io(rw.particles, mem, S_CLD_F, as->cld_frac, nlay * ncol * E, (const void **)&d.cld_frac));
         TRY(st.out(mem, S_CLD_COVER, lw ? as->cld_cover_lw : as->cld_cover_sw, ncol * E, (void **)&d.cld_cover));
     }
     d.aero_size = d.aero_mass = nullptr;
@@ -716,8 +744,8 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
     if (use_aero) {
         RR_CHECK(as->aero_size && as->aero_mass, "aerosol lookup given but the state has no AerosolState");
         const size_t n = (size_t)RRTMGP_N_AEROSOLS * nlay * ncol * E;
-        TRY(st.in(mem, S_AERO_SIZE, as->aero_size, n, (const void **)&d.aero_size));
-        TRY(st.in(mem, S_AERO_MASS, as->aero_mass, n, (const void **)&d.aero_mass));
+        TRY(st.io(rw.particles, mem, S_AERO_SIZE, as->aero_size, n, (const void **)&d.aero_size));
+        TRY(st.io(rw.particles, mem, S_AERO_MASS, as->aero_mass, n, (const void **)&d.aero_mass));
         if (!lw) {
             RR_CHECK((as->aod_sw_ext == nullptr) == (as->aod_sw_sca == nullptr), "aod_sw_ext and aod_sw_sca go together");
             TRY(st.out(mem, S_AOD_EXT, as->aod_sw_ext, ncol * E, (void **)&d.aod_sw_ext));
@@ -729,7 +757,8 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
 
 template <typename FT>
 static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_opts *opts, size_t ncol, size_t nlev,
-                      bool sw, DevFlux<FT> &d, size_t nbnd = 0) {
+                      bool sw, DevFlux<FT> &d, size_t nbnd = 0, int so = 0 /* S_X_FLUX_UP - S_FLUX_UP: the second block of slots */,
+                      const FT *staged_metric = nullptr /* the metric factors are on the device already */) {
     RR_CHECK(f && f->flux_up && f->flux_dn && f->flux_net, "flux outputs: missing array");
     RR_CHECK(f->layout == RRTMGP_LAYOUT_NCOL_NLEV || f->layout == RRTMGP_LAYOUT_NLEV_NCOL, "bad flux layout");
     const size_t bytes = ncol * nlev * sizeof(FT);
@@ -742,11 +771,11 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
         if (strided) return st.out2d(slot, p, ncol * sizeof(FT), nlev, fcols * sizeof(FT), (void **)dev);
         return st.out(f->mem, slot, p, bytes, (void **)dev);
     };
-    TRY(flux_out(S_FLUX_UP, f->flux_up, &d.up));
-    TRY(flux_out(S_FLUX_DN, f->flux_dn, &d.dn));
-    TRY(flux_out(S_FLUX_NET, f->flux_net, &d.net));
+    TRY(flux_out(S_FLUX_UP + so, f->flux_up, &d.up));
+    TRY(flux_out(S_FLUX_DN + so, f->flux_dn, &d.dn));
+    TRY(flux_out(S_FLUX_NET + so, f->flux_net, &d.net));
     d.dir = nullptr;
-    if (sw) TRY(flux_out(S_FLUX_DIR, f->flux_dn_dir, &d.dir));
+    if (sw) TRY(flux_out(S_FLUX_DIR + so, f->flux_dn_dir, &d.dir));
     d.layout = f->layout;
     d.band_up = d.band_dn = d.band_net = nullptr;
     d.band_ncol = (int)ncol;
@@ -759,14 +788,14 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
         d.band_ncol = (int)ncol;  // host blocks are packed in the staging buffers and strided on the way home
         if (bcols != ncol && f->mem == RRTMGP_MEM_HOST) {
             const size_t w = bytes, pitch = bcols * nlev * sizeof(FT);
-            TRY(st.out2d(S_BAND_UP, f->band_flux_up, w, nbnd, pitch, (void **)&d.band_up));
-            TRY(st.out2d(S_BAND_DN, f->band_flux_dn, w, nbnd, pitch, (void **)&d.band_dn));
-            if (f->band_flux_net) TRY(st.out2d(S_BAND_NET, f->band_flux_net, w, nbnd, pitch, (void **)&d.band_net));
+            TRY(st.out2d(S_BAND_UP + so, f->band_flux_up, w, nbnd, pitch, (void **)&d.band_up));
+            TRY(st.out2d(S_BAND_DN + so, f->band_flux_dn, w, nbnd, pitch, (void **)&d.band_dn));
+            if (f->band_flux_net) TRY(st.out2d(S_BAND_NET + so, f->band_flux_net, w, nbnd, pitch, (void **)&d.band_net));
         } else {
             if (f->mem == RRTMGP_MEM_DEVICE) d.band_ncol = (int)bcols;
-            TRY(st.out(f->mem, S_BAND_UP, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
-            TRY(st.out(f->mem, S_BAND_DN, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
-            if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
+            TRY(st.out(f->mem, S_BAND_UP + so, f->band_flux_up, bytes * nbnd, (void **)&d.band_up));
+            TRY(st.out(f->mem, S_BAND_DN + so, f->band_flux_dn, bytes * nbnd, (void **)&d.band_dn));
+            if (f->band_flux_net) TRY(st.out(f->mem, S_BAND_NET + so, f->band_flux_net, bytes * nbnd, (void **)&d.band_net));
         }
     }
     d.clear_up = d.clear_dn = d.clear_net = d.clear_dir = nullptr;
@@ -774,13 +803,13 @@ static int stage_flux(Stager &st, const rrtmgp_flux_out *f, const rrtmgp_solve_o
         RR_CHECK(nbnd > 0, "the clear-sky diagnostic is only available from the two-stream, non-gray solvers");
         RR_CHECK(f->clear_flux_up && f->clear_flux_dn && f->clear_flux_net && (!sw || f->clear_flux_dn_dir),
                  "clear-sky diagnostic: clear_flux_up / _dn / _net (and _dn_dir for SW) go together");
-        TRY(flux_out(S_CLR_UP, f->clear_flux_up, &d.clear_up));
-        TRY(flux_out(S_CLR_DN, f->clear_flux_dn, &d.clear_dn));
-        TRY(flux_out(S_CLR_NET, f->clear_flux_net, &d.clear_net));
-        if (sw) TRY(flux_out(S_CLR_DIR, f->clear_flux_dn_dir, &d.clear_dir));
+        TRY(flux_out(S_CLR_UP + so, f->clear_flux_up, &d.clear_up));
+        TRY(flux_out(S_CLR_DN + so, f->clear_flux_dn, &d.clear_dn));
+        TRY(flux_out(S_CLR_NET + so, f->clear_flux_net, &d.clear_net));
+        if (sw) TRY(flux_out(S_CLR_DIR + so, f->clear_flux_dn_dir, &d.clear_dir));
     }
-    d.metric = nullptr;
-    if (opts && opts->metric_scaling)
+    d.metric = staged_metric;
+    if (!staged_metric && opts && opts->metric_scaling)
         TRY(st.in(opts->metric_mem, S_METRIC, opts->metric_scaling, bytes, (const void **)&d.metric));
     return RRTMGP_OK;
 }
@@ -901,7 +930,11 @@ static void slice_state(rrtmgp_atmos_state &a, const ColumnSlice &s, size_t nc) 
     a.aero_size = s.adv(a.aero_size, RRTMGP_N_AEROSOLS * nlay); a.aero_mass = s.adv(a.aero_mass, RRTMGP_N_AEROSOLS * nlay);
     a.aod_sw_ext = s.adv(a.aod_sw_ext, 1); a.aod_sw_sca = s.adv(a.aod_sw_sca, 1);
 }
-static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev, size_t ncol_total) {
+static void slice_opts(rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev) {
+    o.metric_scaling = s.adv(o.metric_scaling, nlev);
+    o.col_offset += (int64_t)s.c0;
+}
+static void slice_flux_arrays(rrtmgp_flux_out &f, const ColumnSlice &s, size_t nlev, size_t ncol_total) {
     // (nlev, ncol): a contiguous slab, nlev values per column; (ncol, nlev): the block starts c0 elements in and keeps
     // the row length of the whole array
     size_t per_col = nlev;
@@ -918,8 +951,10 @@ static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSli
     }
     f.clear_flux_up = s.adv(f.clear_flux_up, per_col); f.clear_flux_dn = s.adv(f.clear_flux_dn, per_col);
     f.clear_flux_net = s.adv(f.clear_flux_net, per_col); f.clear_flux_dn_dir = s.adv(f.clear_flux_dn_dir, per_col);
-    o.metric_scaling = s.adv(o.metric_scaling, nlev);
-    o.col_offset += (int64_t)s.c0;
+}
+static void slice_flux(rrtmgp_flux_out &f, rrtmgp_solve_opts &o, const ColumnSlice &s, size_t nlev, size_t ncol_total) {
+    slice_flux_arrays(f, s, nlev, ncol_total);
+    slice_opts(o, s, nlev);
 }
 
 // `ncol` = columns of the array being sliced (the leading dimension of its inc_flux unless the caller gave one)
@@ -974,12 +1009,10 @@ static int pipeline_resources(rrtmgp_workspace *ws) {
     return RRTMGP_OK;
 }
 
-// `solve_chunk(as_c, flux_c, opts_c, slice, stager)` stages and launches one chunk
+// `chunk(slice, n_columns, stager, vmr_is_gm)` stages and launches the columns [slice.c0, slice.c0 + n_columns)
 template <typename F>
-static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_flux_out *flux,
-                             const rrtmgp_solve_opts *opts, size_t E, F &&solve_chunk) {
+static int run_column_pipeline(rrtmgp_workspace *ws, size_t ncol, size_t E, bool vmr_gm, F &&chunk) {
     TRY(pipeline_resources(ws));
-    const size_t ncol = as->ncol, nlev = as->nlay + 1;
     // chunk size: small enough that the first upload and the last download (the only copies nothing overlaps) are a
     // small share, large enough that every chunk still fills the persistent grid several times over
     static const size_t per_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 8192;
@@ -993,12 +1026,6 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
         const size_t c0 = std::min(ncol, per * c), c1 = std::min(ncol, per * (c + 1));
         if (c1 == c0) break;
         ColumnSlice sl{E, c0};
-        rrtmgp_atmos_state a = *as;
-        rrtmgp_flux_out f = *flux;
-        rrtmgp_solve_opts o{};
-        if (opts) o = *opts; else o.n_gauss_angles = 1;
-        slice_state(a, sl, c1 - c0);
-        slice_flux(f, o, sl, nlev, ncol);
         std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
         Stager st{ws, {}};
         st.cs = ws->copy_stream;
@@ -1007,8 +1034,8 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
         // for a workgroup slot of the persistent solve grid (0.3 ms per chunk in the copy queue: rocprofv3 timeline,
         // tools/experiments/host_timeline.sh)
         static const bool restage_all = getenv("RRTMGP_HIP_HOST_RESTAGE_ALL") != nullptr;
-        if (!restage_all && c >= 2 && a.vmr_kind == RRTMGP_VMR_GM) st.keep |= 1ull << S_VMR;
-        rc = solve_chunk(a, f, o, sl, st);
+        if (!restage_all && c >= 2 && vmr_gm) st.keep |= 1ull << S_VMR;
+        rc = chunk(sl, c1 - c0, st);
         if (rc == RRTMGP_OK && hipEventRecord(ws->ev_k[c & 1], ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipEventRecord");
         // chunk c - 1: its kernel is older than chunk c's, wait for it on the copy stream and bring the fluxes home
         if (rc == RRTMGP_OK && c > 0) {
@@ -1025,6 +1052,21 @@ static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as,
     (void)hipStreamSynchronize(ws->copy_stream);
     (void)hipStreamSynchronize(ws->stream);
     return rc;
+}
+// one solver: `solve_chunk(as_c, flux_c, opts_c, slice, stager)` stages and launches one chunk
+template <typename F>
+static int run_host_pipeline(rrtmgp_workspace *ws, const rrtmgp_atmos_state *as, const rrtmgp_flux_out *flux,
+                             const rrtmgp_solve_opts *opts, size_t E, F &&solve_chunk) {
+    const size_t nlev = as->nlay + 1, ncol = as->ncol;
+    return run_column_pipeline(ws, ncol, E, as->vmr_kind == RRTMGP_VMR_GM, [&](const ColumnSlice &sl, size_t nc, Stager &st) {
+        rrtmgp_atmos_state a = *as;
+        rrtmgp_flux_out f = *flux;
+        rrtmgp_solve_opts o{};
+        if (opts) o = *opts; else o.n_gauss_angles = 1;
+        slice_state(a, sl, nc);
+        slice_flux(f, o, sl, nlev, ncol);
+        return solve_chunk(a, f, o, sl, st);
+    });
 }
 
 // Below this many staged host bytes a solve goes through the bounce buffer (Stager::packed): per-array DMA commands
@@ -1300,6 +1342,244 @@ static int heating_rate_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t
     return st.finish();
 }
 
+
+// ---- the whole radiation step: update_fluxes!(s) (src/api/update_fluxes.jl:223-233) in one call ---------------------------
+// net_flux (nlev, ncol) = lw_net + sw_net, whatever the layout of the two (transpose_sum_into!, Fluxes.jl:407-424)
+template <typename FT>
+__global__ void net_sum_kernel(const FT *a, const FT *b, FT *out, int ncol, int nlev, int layout, int lda, int ldb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ncol * nlev) return;
+    const size_t col = i / nlev, lev = i - col * nlev;
+    const size_t ia = layout == RRTMGP_LAYOUT_NCOL_NLEV ? col + (size_t)lda * lev : i;
+    const size_t ib = layout == RRTMGP_LAYOUT_NCOL_NLEV ? col + (size_t)ldb * lev : i;
+    out[i] = a[ia] + b[ib];
+}
+template <typename FT>
+static int launch_net_sum(rrtmgp_workspace *ws, const FT *a, const FT *b, FT *out, size_t ncol, size_t nlev, int layout, int lda, int ldb) {
+    const size_t n = ncol * nlev;
+    hipLaunchKernelGGL(net_sum_kernel<FT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws->stream, a, b, out, (int)ncol, (int)nlev,
+                       layout, lda, ldb);
+    RR_HIP(hipGetLastError());
+    return RRTMGP_OK;
+}
+
+template <typename FT>
+struct StepLookups {
+    const DevGas<FT> *lw, *sw;
+    const DevCld<FT> *lw_cld, *sw_cld;
+    const DevAero<FT> *lw_aero, *sw_aero;
+    int lw_max_int, sw_max_int;
+};
+
+// One chunk (or the whole batch) of the step: stage everything once, [prepare] -> LW -> SW -> net sums, copy back.
+template <typename FT>
+static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_update_fluxes_args *a, Stager *chunk = nullptr) {
+    const rrtmgp_atmos_state *as = a->as;
+    const rrtmgp_solve_opts *opts = a->opts;
+    const rrtmgp_prepare_opts *po = a->prepare;
+    const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1;
+    const int twostream_lw = a->lw_solver == RRTMGP_LW_TWOSTREAM;
+    const int n_angles = opts ? opts->n_gauss_angles : 1;
+    RR_CHECK(twostream_lw || (n_angles >= 1 && n_angles <= 4), "n_gauss_angles must be 1..4");
+    RR_CHECK(a->bcs_lw->sfc_emis, "LwBCs: sfc_emis is required");
+    RR_CHECK(a->bcs_sw->cos_zenith && a->bcs_sw->toa_flux && a->bcs_sw->sfc_alb_direct && a->bcs_sw->sfc_alb_diffuse,
+             "SwBCs: cos_zenith, toa_flux and the surface albedos are required");
+    RR_CHECK(a->flux_sw->flux_dn_dir, "FluxSW: flux_dn_dir is required");
+    RR_CHECK((!L.lw_cld || L.lw_cld->nband == L.lw->n_bnd) && (!L.sw_cld || L.sw_cld->nband == L.sw->n_bnd),
+             "cloud lookup band count differs from the gas lookup");
+    RR_CHECK((!L.lw_aero || L.lw_aero->nband == L.lw->n_bnd) && (!L.sw_aero || L.sw_aero->nband == L.sw->n_bnd),
+             "aerosol lookup band count differs from the gas lookup");
+    RR_CHECK(a->flux_lw->layout == a->flux_sw->layout, "flux_lw and flux_sw must share one layout");
+    Stager own{ws, {}};
+    Stager &st = chunk ? *chunk : own;
+    const bool use_cld = L.lw_cld || L.sw_cld, use_aero = L.lw_aero || L.sw_aero;
+    const bool prep = po != nullptr;
+    const bool iso = prep && (po->steps & RRTMGP_PREP_ISOTHERMAL) && po->isothermal_boundary_layer;
+    const int mem = as->mem;
+
+    // ---- the state, once.  stage_state as the LW solve stages it (t_lev included; cld_cover = the LW cover) ...
+    DevState<FT> ds;
+    const int64_t nrgh = std::min<int64_t>(L.lw_cld ? L.lw_cld->nrghice : INT32_MAX, L.sw_cld ? L.sw_cld->nrghice : INT32_MAX);
+    rrtmgp_atmos_state as_lw = *as;
+    if (!L.lw_cld) as_lw.cld_cover_lw = nullptr;   // a LW solve without clouds writes no cover: nothing to bring back
+    TRY(stage_state(st, &as_lw, use_cld, use_aero, true, ds, use_cld ? nrgh : 1, StateRW{prep, iso}));
+    // ... and what only the SW solve writes
+    DevState<FT> ds_sw = ds;
+    ds_sw.cld_cover = nullptr;
+    if (L.sw_cld) TRY(st.out(mem, S_CLD_COVER2, as->cld_cover_sw, ncol * E, (void **)&ds_sw.cld_cover));
+    if (L.sw_aero) {
+        RR_CHECK((as->aod_sw_ext == nullptr) == (as->aod_sw_sca == nullptr), "aod_sw_ext and aod_sw_sca go together");
+        TRY(st.out(mem, S_AOD_EXT, as->aod_sw_ext, ncol * E, (void **)&ds_sw.aod_sw_ext));
+        TRY(st.out(mem, S_AOD_SCA, as->aod_sw_sca, ncol * E, (void **)&ds_sw.aod_sw_sca));
+    }
+    // ... and what only the preparation touches
+    PrepView<FT> pv{};
+    if (prep) {
+        RR_CHECK(a->params, "update_fluxes: `params` is required with `prepare`");
+        RR_CHECK(as->p_lev, "prepare_atmosphere: p_lev is required");
+        pv.ncol = (int)ncol; pv.nlay = (int)nlay; pv.ls = 4;
+        FT *ld = const_cast<FT *>(ds.layerdata);
+        pv.col_dry = ld; pv.p_lay = ld + 1; pv.t_lay = ld + 2; pv.rel_hum = ld + 3;
+        TRY(st.inout(mem, S_PLEV, as->p_lev, nlev * ncol * E, (void **)&pv.p_lev));
+        pv.t_lev = const_cast<FT *>(ds.t_lev);
+        pv.t_sfc = ds.t_sfc;
+        TRY(st.in(mem, S_LAT, as->lat, ncol * E, (const void **)&pv.lat));
+        if (as->vmr_kind == RRTMGP_VMR_GM) {
+            pv.vmr_h2o = const_cast<FT *>(ds.vmr_h2o); pv.vmr_o3 = const_cast<FT *>(ds.vmr_o3); pv.hs = 1;
+        } else {
+            RR_CHECK(po->idx_h2o >= 1 && po->idx_h2o <= as->ngas, "Vmr: idx_h2o out of range");
+            pv.vmr_full = const_cast<FT *>(ds.vmr);
+            pv.ngas = (int)as->ngas; pv.hs = (int)as->ngas; pv.vmr_h2o = pv.vmr_full + (po->idx_h2o - 1);
+        }
+        if (iso) {
+            if (use_cld) {
+                pv.cld[0] = const_cast<FT *>(ds.cld_r_eff_liq); pv.cld[1] = const_cast<FT *>(ds.cld_r_eff_ice);
+                pv.cld[2] = const_cast<FT *>(ds.cld_path_liq); pv.cld[3] = const_cast<FT *>(ds.cld_path_ice);
+                pv.cld[4] = const_cast<FT *>(ds.cld_frac);
+            }
+            if (use_aero) { pv.aero[0] = const_cast<FT *>(ds.aero_size); pv.aero[1] = const_cast<FT *>(ds.aero_mass); }
+        }
+        TRY(st.in(po->z_mem, S_ZC, po->center_z, nlay * ncol * E, (const void **)&pv.center_z));
+        TRY(st.in(po->z_mem, S_ZF, po->face_z, nlev * ncol * E, (const void **)&pv.face_z));
+    }
+
+    // ---- boundary conditions
+    const FT *emis, *inc, *mu0, *toa, *adir, *adif;
+    const rrtmgp_lw_bcs *bl = a->bcs_lw;
+    const rrtmgp_sw_bcs *bs = a->bcs_sw;
+    TRY(st.in(bl->mem, S_LW_BC0, bl->sfc_emis, (size_t)L.lw->n_bnd * ncol * E, (const void **)&emis));
+    const size_t inc_ld_in = bl->inc_flux_ld > 0 ? (size_t)bl->inc_flux_ld : ncol;
+    RR_CHECK(!bl->inc_flux || inc_ld_in >= ncol, "LwBCs.inc_flux_ld is smaller than ncol");
+    int inc_ld = (int)ncol;
+    if (bl->inc_flux && inc_ld_in != ncol && bl->mem == RRTMGP_MEM_HOST) {
+        TRY(st.in2d(S_LW_BC1, bl->inc_flux, ncol * E, (size_t)L.lw->n_gpt, inc_ld_in * E, (const void **)&inc));
+    } else {
+        if (bl->inc_flux && bl->mem == RRTMGP_MEM_DEVICE) inc_ld = (int)inc_ld_in;
+        TRY(st.in(bl->mem, S_LW_BC1, bl->inc_flux, (size_t)L.lw->n_gpt * ncol * E, (const void **)&inc));
+    }
+    TRY(st.in(bs->mem, S_BC0, bs->cos_zenith, ncol * E, (const void **)&mu0));
+    TRY(st.in(bs->mem, S_BC1, bs->toa_flux, ncol * E, (const void **)&toa));
+    TRY(st.in(bs->mem, S_BC2, bs->sfc_alb_direct, (size_t)L.sw->n_bnd * ncol * E, (const void **)&adir));
+    TRY(st.in(bs->mem, S_BC3, bs->sfc_alb_diffuse, (size_t)L.sw->n_bnd * ncol * E, (const void **)&adif));
+
+    // ---- outputs
+    DevFlux<FT> fl_lw, fl_sw;
+    TRY(stage_flux(st, a->flux_lw, opts, ncol, nlev, false, fl_lw, twostream_lw ? (size_t)L.lw->n_bnd : (a->flux_lw->clear_flux_up ? 1 : 0)));
+    TRY(stage_flux(st, a->flux_sw, opts, ncol, nlev, true, fl_sw, (size_t)L.sw->n_bnd, S_X_FLUX_UP - S_FLUX_UP, fl_lw.metric));
+    if (!fl_lw.metric) fl_sw.metric = nullptr;
+    // (decided from the caller's descriptors: in the registration pass the staged pointers are all null)
+    const bool band_lw = a->flux_lw->band_flux_up != nullptr, band_sw = a->flux_sw->band_flux_up != nullptr;
+    RR_CHECK(twostream_lw || !band_lw, "per-band fluxes are only available from the two-stream solvers");
+    const bool diag_lw = a->flux_lw->clear_flux_up != nullptr, diag_sw = a->flux_sw->clear_flux_up != nullptr;
+    RR_CHECK(!(diag_lw || diag_sw) || (L.lw_cld && L.sw_cld), "the clear-sky diagnostic needs the cloud lookups (AllSkyRadiationWithClearSkyDiagnostics)");
+    RR_CHECK(!a->clear_net_flux || (diag_lw && diag_sw), "clear_net_flux needs the clear-sky fluxes of both solvers");
+    FT *net = nullptr, *clear_net = nullptr;
+    TRY(st.out(a->flux_lw->mem, S_NET, a->net_flux, ncol * nlev * E, (void **)&net));
+    TRY(st.out(a->flux_lw->mem, S_CLR_NETSUM, a->clear_net_flux, ncol * nlev * E, (void **)&clear_net));
+    if (st.pin_only) return RRTMGP_OK;
+
+    if (chunk && !st.packed) {  // pipelined host path: the uploads ran on the copy stream
+        RR_HIP(hipEventRecord(ws->ev_in[0], st.copy_stream()));
+        RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[0], 0));
+    }
+    TRY(st.flush());  // packed small step: the one upload
+
+    // ---- [prepare] -> LW -> SW -> net, all on the workspace stream
+    if (prep) TRY(launch_prepare<FT>(ws, pv, *a->params, *po, false));
+    const uint64_t seed = opts ? opts->seed : 0;
+    const int64_t coff = opts ? opts->col_offset : 0;
+    // the clear-sky fluxes ride in the same launch when the solver is two-stream and no per-band fluxes are kept;
+    // otherwise the cloudless solve runs first on the same staged state (update_fluxes.jl:39-65, :101-128)
+    auto clear_first = [](DevFlux<FT> &f) {
+        DevFlux<FT> c = f;
+        c.up = f.clear_up; c.dn = f.clear_dn; c.net = f.clear_net; c.dir = f.clear_dir;
+        c.band_up = c.band_dn = c.band_net = nullptr;
+        c.clear_up = c.clear_dn = c.clear_net = c.clear_dir = nullptr;
+        f.clear_up = f.clear_dn = f.clear_net = f.clear_dir = nullptr;
+        return c;
+    };
+    FT *lw_clear_net = fl_lw.clear_net, *sw_clear_net = fl_sw.clear_net;
+    if (diag_lw && (!twostream_lw || band_lw)) {
+        const DevFlux<FT> c = clear_first(fl_lw);
+        TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, nullptr, L.lw_aero, ds, emis, inc, inc_ld, c, n_angles, seed, coff, L.lw_max_int));
+    }
+    TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, L.lw_cld, L.lw_aero, ds, emis, inc, inc_ld, fl_lw, n_angles, seed, coff, L.lw_max_int));
+    if (diag_sw && band_sw) {
+        const DevFlux<FT> c = clear_first(fl_sw);
+        DevState<FT> dc = ds_sw;
+        dc.aod_sw_ext = dc.aod_sw_sca = nullptr;   // the all-sky solve writes the same values
+        TRY(launch_sw<FT>(ws, 1, *L.sw, nullptr, L.sw_aero, dc, mu0, toa, adir, adif, c, seed, coff, L.sw_max_int));
+    }
+    TRY(launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int));
+    if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
+    if (clear_net) TRY(launch_net_sum<FT>(ws, lw_clear_net, sw_clear_net, clear_net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
+    return chunk && !st.packed ? RRTMGP_OK : st.finish();
+}
+
+// The column range [sl.c0, sl.c0 + nc) of every array of a step
+struct StepSlice {
+    rrtmgp_update_fluxes_args a;
+    rrtmgp_atmos_state as;
+    rrtmgp_lw_bcs bl;
+    rrtmgp_sw_bcs bs;
+    rrtmgp_flux_out fl, fs;
+    rrtmgp_solve_opts o;
+    rrtmgp_prepare_opts po;
+    StepSlice(const rrtmgp_update_fluxes_args *src, const ColumnSlice &sl, size_t nc, size_t nb_lw, size_t nb_sw) {
+        a = *src; as = *src->as; bl = *src->bcs_lw; bs = *src->bcs_sw; fl = *src->flux_lw; fs = *src->flux_sw;
+        o = rrtmgp_solve_opts{};
+        if (src->opts) o = *src->opts; else o.n_gauss_angles = 1;
+        const size_t ncol = (size_t)src->as->ncol, nlay = (size_t)src->as->nlay, nlev = nlay + 1;
+        slice_state(as, sl, nc);
+        slice_lw_bcs(bl, sl, nb_lw, ncol);
+        slice_sw_bcs(bs, sl, nb_sw);
+        slice_flux_arrays(fl, sl, nlev, ncol);
+        slice_flux_arrays(fs, sl, nlev, ncol);
+        slice_opts(o, sl, nlev);
+        a.net_flux = sl.adv(a.net_flux, nlev); a.clear_net_flux = sl.adv(a.clear_net_flux, nlev);
+        if (src->prepare) {
+            po = *src->prepare;
+            po.center_z = sl.adv(po.center_z, nlay); po.face_z = sl.adv(po.face_z, nlev);
+            a.prepare = &po;
+        }
+        a.as = &as; a.bcs_lw = &bl; a.bcs_sw = &bs; a.flux_lw = &fl; a.flux_sw = &fs; a.opts = &o;
+    }
+    StepSlice(const StepSlice &) = delete;
+};
+
+template <typename FT>
+static int step_host(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_update_fluxes_args *a) {
+    size_t need = 0;
+    PinScope scope{ws};
+    {   // registration pass over the caller's whole host arrays
+        host_pin_begin(ws);
+        Stager pin{ws, {}};
+        pin.pin_only = true;
+        TRY(step_t<FT>(ws, L, a, &pin));
+        need = pin.need;
+    }
+    const rrtmgp_solve_opts *o = a->opts;
+    const bool all_host = a->as->mem == RRTMGP_MEM_HOST && a->bcs_lw->mem == RRTMGP_MEM_HOST && a->bcs_sw->mem == RRTMGP_MEM_HOST &&
+                          a->flux_lw->mem == RRTMGP_MEM_HOST && a->flux_sw->mem == RRTMGP_MEM_HOST &&
+                          (!o || !o->metric_scaling || o->metric_mem == RRTMGP_MEM_HOST) &&
+                          (!a->prepare || (!a->prepare->center_z && !a->prepare->face_z) || a->prepare->z_mem == RRTMGP_MEM_HOST);
+    static const bool no_pipe = getenv("RRTMGP_HIP_NO_HOST_PIPELINE") != nullptr;
+    if (no_pipe || !all_host || a->as->ncol < 16384) {
+        if (need && need <= host_pack_max()) {   // small step: one bounce buffer, one DMA each way
+            TRY(bounce_ensure(ws, need));
+            Stager st{ws, {}};
+            st.packed = true;
+            return step_t<FT>(ws, L, a, &st);
+        }
+        return step_t<FT>(ws, L, a);
+    }
+    return run_column_pipeline(ws, (size_t)a->as->ncol, sizeof(FT), a->as->vmr_kind == RRTMGP_VMR_GM,
+                               [&](const ColumnSlice &sl, size_t nc, Stager &st) {
+                                   StepSlice c(a, sl, nc, (size_t)L.lw->n_bnd, (size_t)L.sw->n_bnd);
+                                   return step_t<FT>(ws, L, &c.a, &st);
+                               });
+}
+
 }  // namespace rrtmgp
 
 using namespace rrtmgp;
@@ -1571,6 +1851,67 @@ int rrtmgp_hip_rte_sw_noscat_solve(rrtmgp_workspace *ws, const rrtmgp_lookup *lo
 
 }  // extern "C"
 
+// update_fluxes!(s::RRTMGPSolver, seedval)  src/api/update_fluxes.jl:223-233
+static int step_dispatch(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_args *a) {
+    if (ws->ftype == RRTMGP_F32) {
+        const StepLookups<float> L{&a->lookup_lw->gas32, &a->lookup_sw->gas32,
+                                   a->lookup_lw_cld ? &a->lookup_lw_cld->cld32 : nullptr, a->lookup_sw_cld ? &a->lookup_sw_cld->cld32 : nullptr,
+                                   a->lookup_lw_aero ? &a->lookup_lw_aero->aero32 : nullptr, a->lookup_sw_aero ? &a->lookup_sw_aero->aero32 : nullptr,
+                                   a->lookup_lw->max_int, a->lookup_sw->max_int};
+        return step_host<float>(ws, L, a);
+    }
+    const StepLookups<double> L{&a->lookup_lw->gas64, &a->lookup_sw->gas64,
+                                a->lookup_lw_cld ? &a->lookup_lw_cld->cld64 : nullptr, a->lookup_sw_cld ? &a->lookup_sw_cld->cld64 : nullptr,
+                                a->lookup_lw_aero ? &a->lookup_lw_aero->aero64 : nullptr, a->lookup_sw_aero ? &a->lookup_sw_aero->aero64 : nullptr,
+                                a->lookup_lw->max_int, a->lookup_sw->max_int};
+    return step_host<double>(ws, L, a);
+}
+
+extern "C" {
+
+int rrtmgp_hip_update_fluxes(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_args *a) {
+    RR_CHECK(ws && a, "null argument");
+    RR_CHECK(a->lookup_lw && a->lookup_sw && a->as && a->bcs_lw && a->bcs_sw && a->flux_lw && a->flux_sw,
+             "update_fluxes: lookups, state, boundary conditions and flux outputs are required");
+    RR_CHECK(a->lw_solver == RRTMGP_LW_TWOSTREAM || a->lw_solver == RRTMGP_LW_NOSCAT, "lw_solver must be RRTMGP_LW_TWOSTREAM or RRTMGP_LW_NOSCAT");
+    const rrtmgp_solve_opts *o = a->opts;
+    if (!ws->shards.empty()) {
+        RR_CHECK(a->lookup_lw->kind == LK_GAS && a->lookup_lw->ftype == ws->ftype && a->lookup_sw->kind == LK_GAS && a->lookup_sw->ftype == ws->ftype,
+                 "expected gas lookups of the workspace's precision");
+        RR_CHECK(a->as->ncol == ws->ncol && a->as->nlay == ws->nlay, "state dimensions differ from the workspace");
+        TRY(check_multi(ws, a->as->mem, a->bcs_lw->mem, a->flux_lw, o, nullptr));
+        TRY(check_multi(ws, a->as->mem, a->bcs_sw->mem, a->flux_sw, o, nullptr));
+        const bool dev_arrays = a->as->mem == RRTMGP_MEM_DEVICE || a->bcs_lw->mem == RRTMGP_MEM_DEVICE || a->bcs_sw->mem == RRTMGP_MEM_DEVICE ||
+                                a->flux_lw->mem == RRTMGP_MEM_DEVICE || a->flux_sw->mem == RRTMGP_MEM_DEVICE ||
+                                (o && o->metric_scaling && o->metric_mem == RRTMGP_MEM_DEVICE);
+        const size_t E = (size_t)ws->ftype, nb_lw = (size_t)n_bnd_of(ws, a->lookup_lw), nb_sw = (size_t)n_bnd_of(ws, a->lookup_sw);
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            StepSlice c(a, ColumnSlice{E, c0}, nc, nb_lw, nb_sw);
+            const rrtmgp_lookup **lk[6] = {&c.a.lookup_lw, &c.a.lookup_sw, &c.a.lookup_lw_cld, &c.a.lookup_sw_cld, &c.a.lookup_lw_aero, &c.a.lookup_sw_aero};
+            for (auto *p : lk) {
+                if (!*p) continue;
+                *p = lookup_on(*p, sw->device);
+                if (!*p) return set_error(RRTMGP_EINVAL, "a lookup has no replica on one of the workspace's devices (use *_lookup_create_multi)");
+            }
+            return rrtmgp_hip_update_fluxes(sw, &c.a);
+        }, dev_arrays);
+    }
+    TRY(check_common(ws, a->lookup_lw, 0, a->lookup_lw_cld, a->lookup_lw_aero, a->as));
+    TRY(check_common(ws, a->lookup_sw, 1, a->lookup_sw_cld, a->lookup_sw_aero, a->as));
+    return step_dispatch(ws, a);
+}
+
+int rrtmgp_hip_workspace_transfer_bytes(const rrtmgp_workspace *ws, uint64_t *h2d, uint64_t *d2h) {
+    RR_CHECK(ws, "null workspace");
+    uint64_t a = ws->h2d_bytes, b = ws->d2h_bytes;
+    for (const rrtmgp_workspace *s : ws->shards) { a += s->h2d_bytes; b += s->d2h_bytes; }
+    if (h2d) *h2d = a;
+    if (d2h) *d2h = b;
+    return RRTMGP_OK;
+}
+
+}  // extern "C"
+
 // gray solves / preparation steps on a multi-device workspace: same slicing, no lookups
 template <typename BCS, typename SliceBcs, typename Call>
 static int multi_gray(rrtmgp_workspace *ws, const rrtmgp_gray_state *gs, const BCS *bcs, const rrtmgp_flux_out *flux,
@@ -1783,7 +2124,7 @@ const char *rrtmgp_hip_build_flags(void) {
     return s.c_str();
 }
 const char *rrtmgp_hip_version(void) {
-    static const std::string s = std::string("0.3.0") + (*rrtmgp_hip_build_flags() ? std::string(" [") + rrtmgp_hip_build_flags() + "]" : std::string());
+    static const std::string s = std::string("0.4.0") + (*rrtmgp_hip_build_flags() ? std::string(" [") + rrtmgp_hip_build_flags() + "]" : std::string());
     return s.c_str();
 }
 
@@ -1803,6 +2144,7 @@ int rrtmgp_hip_abi_sizeof(int which) {
         case 10: return (int)sizeof(rrtmgp_params);
         case 11: return (int)sizeof(rrtmgp_prepare_opts);
         case 12: return (int)sizeof(rrtmgp_view2d);
+        case 13: return (int)sizeof(rrtmgp_update_fluxes_args);
         default: return -1;
     }
 }

@@ -152,6 +152,8 @@ struct rrtmgp_workspace {
     // DMA each way) instead of one DMA per array (~15 us each, 17 arrays per solve)
     char *bounce_h = nullptr, *bounce_d = nullptr;
     size_t bounce_bytes = 0;
+    // bytes staged host -> device / device -> host since creation (rrtmgp_hip_workspace_transfer_bytes)
+    uint64_t h2d_bytes = 0, d2h_bytes = 0;
     // per-(block, level, lane) scratch of the vertical sweeps
     rrtmgp::DeviceBuffer scratch;
     // resident workgroups per CU of each (kernel, dynamic LDS size) launched so far

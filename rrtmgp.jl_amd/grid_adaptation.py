@@ -95,13 +95,11 @@ def update_concentrations(ws, as_, params, idx_h2o=1):
     return _run(ws, as_, params, make_prepare_opts(_abi.PREP_COL_DRY, idx_h2o=idx_h2o))
 
 
-def prepare_atmosphere(ws, as_, params, lookup_lw=None, interpolation=NoInterpolation,
-                       bottom_extrapolation=SameAsInterpolation, isothermal_boundary_layer=False, center_z=None,
-                       face_z=None, relative_humidity=False):
-    """The whole cascade in one launch (update_fluxes.jl:252-281).  Bounds come from the longwave
-    lookup (get_p_min / get_t_min / get_t_max, grid_adaptation.jl:22-53); gray states get p_min = 0
-    and no temperature clamp.  `relative_humidity=True` also refreshes layerdata row 4 from the clipped state in
-    the same launch (compute_relative_humidity!, which the reference's drivers call separately)."""
+def prepare_atmosphere_opts(as_, lookup_lw=None, interpolation=NoInterpolation, bottom_extrapolation=SameAsInterpolation,
+                            isothermal_boundary_layer=False, center_z=None, face_z=None,
+                            relative_humidity=False) -> _abi.PrepareOpts:
+    """The options of the whole cascade (update_fluxes.jl:252-281).  Bounds come from the longwave lookup (get_p_min /
+    get_t_min / get_t_max, grid_adaptation.jl:22-53); gray states get p_min = 0 and no temperature clamp."""
     gray = isinstance(as_, GrayAtmosphericState)
     if not gray and lookup_lw is None:
         raise ValueError("a spectral state needs `lookup_lw` for its pressure / temperature bounds")
@@ -111,6 +109,15 @@ def prepare_atmosphere(ws, as_, params, lookup_lw=None, interpolation=NoInterpol
     steps = _abi.PREP_ALL if interpolation != NoInterpolation else _abi.PREP_ALL & ~_abi.PREP_INTERPOLATE
     if relative_humidity and not gray:
         steps |= _abi.PREP_REL_HUM
-    return _run(ws, as_, params, make_prepare_opts(steps, interpolation, bottom_extrapolation,
-                                                   isothermal_boundary_layer, center_z, face_z, p_min, t_min, t_max,
-                                                   idx_h2o))
+    return make_prepare_opts(steps, interpolation, bottom_extrapolation, isothermal_boundary_layer, center_z, face_z, p_min,
+                             t_min, t_max, idx_h2o)
+
+
+def prepare_atmosphere(ws, as_, params, lookup_lw=None, interpolation=NoInterpolation,
+                       bottom_extrapolation=SameAsInterpolation, isothermal_boundary_layer=False, center_z=None,
+                       face_z=None, relative_humidity=False):
+    """The whole cascade in one launch (update_fluxes.jl:252-281).  `relative_humidity=True` also refreshes layerdata
+    row 4 from the clipped state in the same launch (compute_relative_humidity!, which the reference's drivers call
+    separately)."""
+    return _run(ws, as_, params, prepare_atmosphere_opts(as_, lookup_lw, interpolation, bottom_extrapolation,
+                                                         isothermal_boundary_layer, center_z, face_z, relative_humidity))

@@ -104,6 +104,12 @@ class Workspace:
         _lib.check(_lib.lib().rrtmgp_hip_workspace_last_kernel_ms(self.handle, C.byref(ms)), "last_kernel_ms")
         return ms.value
 
+    def transfer_bytes(self):
+        """(host -> device, device -> host) bytes this workspace has staged since it was created."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().rrtmgp_hip_workspace_transfer_bytes(self.handle, C.byref(a), C.byref(b)), "transfer_bytes")
+        return a.value, b.value
+
     def __del__(self):
         try:
             if self.handle:
@@ -236,6 +242,53 @@ def solve_sw(slv: _RTE, as_, lookup_sw=None, lookup_sw_cld=None, lookup_sw_aero=
         _lib.check(L.rrtmgp_hip_rte_sw_noscat_solve(slv.ws.handle, sw.handle, C.byref(ds), C.byref(db), C.byref(df),
                                                     C.byref(o)), "solve_sw")
     return slv.flux
+
+
+def update_fluxes(lws: _RTE, sws: _RTE, as_, lookup_lw, lookup_sw, lookup_lw_cld=None, lookup_sw_cld=None, lookup_lw_aero=None,
+                  lookup_sw_aero=None, metric_scaling=None, seed: int = 0, col_offset: int = 0, net_flux=None,
+                  clear_flux_lw: Optional[Flux] = None, clear_flux_sw: Optional[Flux] = None, clear_net_flux=None,
+                  params=None, prepare: Optional[_abi.PrepareOpts] = None):
+    """The whole radiation step in ONE call of the library (`rrtmgp_hip_update_fluxes`): the state crosses to the device
+    once, then [`prepare` kernel] -> LW solve -> SW solve -> `net_flux = lw net + sw net` (update_fluxes!,
+    src/api/update_fluxes.jl:223-233).  `lws` / `sws` are the two solver workspaces (they must share one library
+    workspace); `clear_flux_*` receive the clear-sky fluxes of AllSkyRadiationWithClearSkyDiagnostics; `prepare` = the
+    options of prepare_atmosphere! (grid_adaptation.make_prepare_opts), None when the state is already prepared."""
+    if lws.ws is not sws.ws:
+        raise ValueError("update_fluxes: the longwave and the shortwave solver must share one Workspace")
+    if isinstance(as_, GrayAtmosphericState):
+        raise TypeError("update_fluxes is the spectral step; gray radiation goes through solve_lw / solve_sw")
+    if not sws.twostream:
+        raise ValueError("spectral shortwave radiation requires the two-stream solver (solver.jl:176-182)")
+    _check_precision(lws, as_, lookup_lw, lookup_lw_cld, lookup_lw_aero)
+    _check_precision(sws, as_, lookup_sw, lookup_sw_cld, lookup_sw_aero)
+    dev = lws.device
+    lk = [_dev(x, dev) for x in (lookup_lw, lookup_sw, lookup_lw_cld, lookup_sw_cld, lookup_lw_aero, lookup_sw_aero)]
+    a = _abi.UpdateFluxesArgs()
+    (a.lookup_lw, a.lookup_sw, a.lookup_lw_cld, a.lookup_sw_cld, a.lookup_lw_aero, a.lookup_sw_aero) = [_null(x) for x in lk]
+    ds = as_.desc(lk[2] is not None or lk[3] is not None, lk[4] is not None or lk[5] is not None)
+    bl, bs = lws.bcs.desc(), sws.bcs.desc()
+    fl, fs = lws.flux.desc(lws.band_flux, clear_flux_lw), sws.flux.desc(sws.band_flux, clear_flux_sw)
+    o = _opts(lws.n_gauss_angles, metric_scaling, seed, col_offset)
+    a.as_, a.bcs_lw, a.bcs_sw, a.flux_lw, a.flux_sw, a.opts = (C.pointer(ds), C.pointer(bl), C.pointer(bs), C.pointer(fl),
+                                                               C.pointer(fs), C.pointer(o))
+    for name, arr in (("net_flux", net_flux), ("clear_net_flux", clear_net_flux)):
+        if arr is None:
+            continue
+        ptr, mem = array_ptr(arr)
+        if mem != fl.mem:
+            raise ValueError(f"update_fluxes: {name} must live where the flux buffers live")
+        if tuple(julia_shape(arr)) != (lws.ws.nlay + 1, lws.ws.ncol):
+            raise ValueError(f"update_fluxes: {name} must be (nlev, ncol)")
+        setattr(a, name, ptr)
+    keep = None
+    if prepare is not None:
+        if params is None:
+            raise ValueError("update_fluxes: `params` is required with `prepare`")
+        keep = params.desc()
+        a.params, a.prepare = C.pointer(keep), C.pointer(prepare)
+    a.lw_solver = _abi.LW_TWOSTREAM if lws.twostream else _abi.LW_NOSCAT
+    _lib.check(_lib.lib().rrtmgp_hip_update_fluxes(lws.ws.handle, C.byref(a)), "update_fluxes")
+    return lws.flux, sws.flux
 
 
 def _check_extents(ws: Workspace, what: str, **arrays):

@@ -67,7 +67,9 @@ class RRTMGPSolver:
                  lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0,
                  spectral_fluxes: bool = False, interpolation: str = grid_adaptation.NoInterpolation,
                  bottom_extrapolation: str = grid_adaptation.SameAsInterpolation,
-                 isothermal_boundary_layer: bool = False, center_z=None, face_z=None):
+                 isothermal_boundary_layer: bool = False, center_z=None, face_z=None, fused: bool = True):
+        """`fused` (default): `update_fluxes` of a spectral method is ONE call of the library (`rrtmgp_hip_update_fluxes`:
+        state staged once, prepare -> LW -> SW -> net on the device); False runs the reference's four steps as four calls."""
         self.radiation_method, self.params, self.as_ = radiation_method, params, as_
         self.deep_atmosphere_inverse_scaling = deep_atmosphere_inverse_scaling
         self.interpolation, self.bottom_extrapolation = interpolation, bottom_extrapolation
@@ -113,6 +115,7 @@ class RRTMGPSolver:
         self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False) if diag else None
         self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True) if diag else None
         self.clear_net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F") if diag else None
+        self.fused = bool(fused) and not gray
         self._seed = 0       # key of the counter-based McICA stream of the current update_fluxes call
         self._rng_state = 0  # host generator the per-call keys are drawn from (the reference's global `Random` state)
 
@@ -183,10 +186,29 @@ class RRTMGPSolver:
         z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         self._seed = z ^ (z >> 31)
+        if self.fused:
+            self._update_fluxes_fused()
+            return
         self.prepare_atmosphere()
         self.update_lw_fluxes()
         self.update_sw_fluxes()
         self.update_net_fluxes()
+
+    def _update_fluxes_fused(self):
+        """The four steps above as one library call: the state is staged once, `prepare_atmosphere!` runs as a kernel in
+        front of the two solves, the clear-sky diagnostic rides in the all-sky launches, and `net_flux` / `clear_net_flux`
+        are summed on the device (update_fluxes.jl:223-233)."""
+        m, lk = self.radiation_method, self.lookups
+        clouds = not isinstance(m, ClearSkyRadiation)
+        aero = m.aerosol_radiation
+        prep = grid_adaptation.prepare_atmosphere_opts(self.as_, lk.lookup_lw, self.interpolation, self.bottom_extrapolation,
+                                                       self.isothermal_boundary_layer, self.center_z, self.face_z)
+        rte.update_fluxes(self.lws, self.sws, self.as_, lk.lookup_lw, lk.lookup_sw,
+                          lk.lookup_lw_cld if clouds else None, lk.lookup_sw_cld if clouds else None,
+                          lk.lookup_lw_aero if aero else None, lk.lookup_sw_aero if aero else None,
+                          metric_scaling=self.deep_atmosphere_inverse_scaling, seed=self._seed,
+                          net_flux=self.net_flux_buffer, clear_flux_lw=self.clear_flux_lw, clear_flux_sw=self.clear_flux_sw,
+                          clear_net_flux=self.clear_net_flux_buffer, params=self.params, prepare=prep)
 
 
 def update_fluxes(s: RRTMGPSolver, seedval=None):
@@ -257,4 +279,7 @@ def heating_rate(s: RRTMGPSolver):
     """heating_rate (src/api/standalone.jl:100-122): (g / cp) dF_net/dp per layer [K/s]; fresh array.  Like the reference it
     hands `level_pressure(s)` and `net_flux(s)` — domain VIEWS — and the domain layer count to the device method; nothing
     is copied on the way (rrtmgp_view2d)."""
-    return rte.compute_gray_heating_rate(s.lws.ws, level_pressure(s), net_flux(s), s.params.cp_d, s.params.grav)
+    p_lev, f_net = level_pressure(s), net_flux(s)
+    if isinstance(f_net, np.ndarray) and not isinstance(p_lev, np.ndarray):
+        p_lev = to_host(p_lev)   # a device-resident state next to the host flux buffers: one memory kind per call
+    return rte.compute_gray_heating_rate(s.lws.ws, p_lev, f_net, s.params.cp_d, s.params.grav)

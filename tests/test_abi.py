@@ -31,7 +31,7 @@ def test_struct_mirror_matches_compiled_sizes():
     for i, st in enumerate(_lib.ABI_STRUCTS):
         assert L.rrtmgp_hip_abi_sizeof(i) == C.sizeof(st), st.__name__
     assert L.rrtmgp_hip_abi_sizeof(99) == -1
-    assert L.rrtmgp_hip_version() == b"0.3.0"       # no " [flags]" suffix: built as shipped
+    assert L.rrtmgp_hip_version() == b"0.4.0"       # no " [flags]" suffix: built as shipped
 
 
 def test_shipped_library_is_built_without_experiment_switches():
@@ -46,7 +46,7 @@ def test_shipped_library_is_built_without_experiment_switches():
     P = C.CDLL(precise)
     P.rrtmgp_hip_build_flags.restype = C.c_char_p
     P.rrtmgp_hip_version.restype = C.c_char_p
-    assert P.rrtmgp_hip_build_flags() == b"RR_PRECISE_F32" and P.rrtmgp_hip_version() == b"0.3.0 [RR_PRECISE_F32]"
+    assert P.rrtmgp_hip_build_flags() == b"RR_PRECISE_F32" and P.rrtmgp_hip_version() == b"0.4.0 [RR_PRECISE_F32]"
     variants = open(os.path.join(csrc, "variants.h")).read()
     used = set()
     for f in os.listdir(csrc):

@@ -17,7 +17,7 @@ PAIRS = {"MinorDesc": _abi.MinorDesc, "GasLookupDesc": _abi.GasLookupDesc, "Clou
          "AerosolLookupDesc": _abi.AerosolLookupDesc, "AtmosStateDesc": _abi.AtmosState, "LwBcsDesc": _abi.LwBcs,
          "SwBcsDesc": _abi.SwBcs, "FluxOutDesc": _abi.FluxOut, "SolveOpts": _abi.SolveOpts,
          "GrayStateDesc": _abi.GrayState, "ParamsDesc": _abi.Params, "PrepareOpts": _abi.PrepareOpts,
-         "View2D": _abi.View2D}
+         "View2D": _abi.View2D, "UpdateFluxesArgs": _abi.UpdateFluxesArgs}
 SIZES = {"Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "P": 8, "Ptr{Int64}": 8, "MinorDesc": C.sizeof(_abi.MinorDesc),
          "NTuple{5, Float64}": 40}
 
@@ -48,7 +48,8 @@ def test_julia_struct_mirrors_match_ctypes():
     for jl_name, ct in PAIRS.items():
         jf = julia_fields(jl_name)
         cf = list(ct._fields_)
-        assert [f for f, _ in jf] == [f for f, _ in cf], jl_name
+        # (`as` is a Python keyword: the ctypes mirror spells that one field `as_`)
+        assert [f for f, _ in jf] == [f[:-1] if f == "as_" else f for f, _ in cf], jl_name
         for (f, jt), (_, cty) in zip(jf, cf):
             assert SIZES[jt] == C.sizeof(cty), (jl_name, f, jt)
 
@@ -101,8 +102,8 @@ def test_every_identifier_in_every_method_body_resolves():
 
 def test_checker_catches_the_round1_defect():
     """The checker must FAIL on a method that names something it does not have (the round-1 `band_flux` bug)."""
-    broken = JL.replace("flux_desc(flux_lw), opts()))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW",
-                        "flux_desc(flux_lw, band_flux), opts()))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW", 1)
+    broken = JL.replace("set!(sc.flux_lw, flux_desc(flux_lw)), set!(sc.opts, opts())))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW",
+                        "set!(sc.flux_lw, flux_desc(flux_lw, band_flux)), set!(sc.opts, opts())))\n    return nothing\nend\n\nfunction rte_lw_noscat_solve!(dev::HIPDevice, flux_lw::FluxLW", 1)
     assert broken != JL
     bad = _unresolved(broken)
     assert ("rte_lw_2stream_solve!", "band_flux") in {(m, n) for m, n, _ in bad}, bad
@@ -211,11 +212,26 @@ FIELD_HINTS = {
 }
 
 
+# the Layer-2 overrides reach the solver's parts through fields typed by unbounded parameters (src/api/solver.jl:95-134,
+# src/rte/RTE.jl:53-287): what the RRTMGPSolver constructor puts there for spectral radiation
+FIELD_HINTS.update({
+    ("RRTMGPSolver", "grid_params"): ["RRTMGPGridParams"], ("RRTMGPSolver", "as"): ["AtmosphericState"],
+    ("RRTMGPSolver", "lws"): ["TwoStreamLWRTE", "NoScatLWRTE"], ("RRTMGPSolver", "sws"): ["TwoStreamSWRTE"],
+    ("RRTMGPSolver", "lookups"): ["LookupBundle"], ("RRTMGPSolver", "radiation_method"): ["AllSkyRadiation"],
+    ("RRTMGPSolver", "clear_flux_lw"): ["FluxPresentation"], ("RRTMGPSolver", "clear_flux_sw"): ["FluxPresentation"],
+    ("TwoStreamLWRTE", "bcs"): ["LwBCs"], ("NoScatLWRTE", "bcs"): ["LwBCs"], ("TwoStreamSWRTE", "bcs"): ["SwBCs"],
+    ("NoScatLWRTE", "angle_disc"): ["AngularDiscretization"],
+    ("TwoStreamLWRTE", "band_flux"): ["FluxBand"], ("TwoStreamSWRTE", "band_flux"): ["FluxBand"],
+    ("LookupBundle", "lookup_lw"): ["LookUpLW"], ("LookupBundle", "lookup_sw"): ["LookUpSW"],
+})
+TYPE_ALIASES = {"HIPSpectralSolver": ["RRTMGPSolver"]}
+
+
 def _bad_fields(src):
     structs = SIGS["structs"]
     out = []
     for m in JLITE.parse_module(src).methods:
-        out += [(m.name, chain, why) for chain, why, _ in JLITE.bad_field_accesses(m, structs, FIELD_HINTS)]
+        out += [(m.name, chain, why) for chain, why, _ in JLITE.bad_field_accesses(m, structs, FIELD_HINTS, TYPE_ALIASES)]
     return out
 
 
@@ -230,6 +246,18 @@ def test_every_field_access_names_a_field_of_the_reference_struct():
     typed = sum(1 for m in mod.methods for p in m.params if p.type and JLITE._type_structs(p.type, structs))
     assert typed >= 40, typed  # the check is not vacuous: that many parameters carry a reference struct type
     assert _bad_fields(JL) == []
+
+
+def test_field_checker_follows_the_solver_through_the_type_alias():
+    """`s::HIPSpectralSolver` is an RRTMGPSolver: `s.lws.bcs.sfc_emis`, `s.presented_flux_lw.flux_net`, ... are checked too."""
+    broken = JL.replace("set!(sc.bcs_lw, lw_bcs_desc(lws.bcs))\n    set!(sc.bcs_sw, sw_bcs_desc(sws.bcs))",
+                        "set!(sc.bcs_lw, lw_bcs_desc(s.lws.bcs))\n    set!(sc.bcs_sw, sw_bcs_desc(s.sws.boundary))", 1)
+    assert broken != JL
+    assert any(chain == "s.sws.boundary" for _, chain, _ in _bad_fields(broken)), _bad_fields(broken)
+    broken = JL.replace("s.presented_flux_sw.flux_net)", "s.presented_flux_sw.net)", 1)
+    assert broken != JL and any(why == "FluxPresentation has no field net" for _, _, why in _bad_fields(broken))
+    broken = JL.replace("ptr(s.net_flux_buffer)", "ptr(s.net_flux)", 1)
+    assert broken != JL and any(why == "RRTMGPSolver has no field net_flux" for _, _, why in _bad_fields(broken))
 
 
 def test_field_checker_catches_a_wrong_field_name():
@@ -256,7 +284,7 @@ def test_every_imported_and_qualified_reference_name_exists():
             if nm not in mods.get(m.group(1), ()):
                 missing.append(f"{m.group(1)}: {nm}")
     # qualified uses: RRTMGP.<Module>.<name>, RRTMGP.<name>, <alias>.<name>
-    for m in re.finditer(r"\b(RRTMGP(?:\.[A-Z]\w*)*)\.([a-z_][\w!]*|[A-Z]\w*)\b", code):
+    for m in re.finditer(r"\b(RRTMGP(?:\.[A-Z]\w*)*)\.([a-z_][\w!]*|[A-Z]\w*)(?![\w!])", code):
         owner, nm = m.group(1), m.group(2)
         if owner + "." + nm in mods:   # a module path, not a name
             continue
@@ -272,12 +300,69 @@ def test_every_imported_and_qualified_reference_name_exists():
     assert missing == []
 
 
+L2_NAMES = ("update_fluxes!", "update_lw_fluxes!", "update_sw_fluxes!", "update_net_fluxes!", "prepare_atmosphere!")
+
+
+def _layer2_methods(mod):
+    return [m for m in mod.methods if m.name.split(".")[-1] in L2_NAMES and m.params
+            and JLITE.norm_type(m.params[0].type) == "HIPSpectralSolver"]
+
+
+def test_layer2_overrides_have_the_reference_signatures():
+    """update_fluxes!(s, seedval = nothing), prepare_atmosphere!(s), update_lw_fluxes!(s), update_sw_fluxes!(s),
+    update_net_fluxes!(s) (src/api/update_fluxes.jl:12,74,165,223,252; golden index `l2_methods`): the glue specialises each
+    of them on the solver type alone — same name, same positional parameters, same defaults — for solvers whose grid
+    parameters carry a HIPDevice context and whose radiation method is spectral."""
+    mine = {}
+    for m in _layer2_methods(_module()):
+        mine.setdefault(m.name.split(".")[-1], []).append(m)
+    assert set(mine) == set(L2_NAMES), sorted(mine)
+    for name in L2_NAMES:
+        # the reference's entry method of that name: the one that takes the solver and no radiation-method tag
+        refs = [r for r in SIGS["l2_methods"] if r["name"] == name and all(p["name"] for p in r["params"])]
+        assert len(refs) == 1, (name, refs)
+        want = [(p["name"], p["default"]) for p in refs[0]["params"]]
+        (m,) = mine[name]
+        assert [(p.name, p.has_default) for p in m.params] == want, (name, want)
+        assert refs[0]["params"][0]["type"] == "RRTMGPSolver"
+    # the dispatch chain: solver -> grid params -> context -> device, and spectral methods only (gray keeps the generic path)
+    for pat in (r"const HIPContext = ClimaComms\.SingletonCommsContext\{<:HIPDevice\}",
+                r"const HIPGrid = RRTMGP\.RRTMGPGridParams\{<:Any, <:HIPContext\}",
+                r"const SpectralMethod = Union\{RRTMGP\.ClearSkyRadiation, RRTMGP\.AllSkyRadiation, RRTMGP\.AllSkyRadiationWithClearSkyDiagnostics\}",
+                r"const HIPSpectralSolver = RRTMGP\.RRTMGPSolver\{<:HIPGrid, <:SpectralMethod\}"):
+        assert re.search(pat, JL), pat
+    g = SIGS["structs"]["RRTMGPGridParams"]
+    assert list(g["params"]) == ["FT", "C"] and [f for f, _ in g["fields"]][0] == "context"     # {FT, C}: C is the context type
+    sp = list(SIGS["structs"]["RRTMGPSolver"]["params"])
+    assert sp[:2] == ["S", "RM"]                                                               # {S = grid params, RM = method, ...}
+    assert dict(SIGS["structs"]["RRTMGPSolver"]["fields"])["grid_params"] == "S"
+    assert dict(SIGS["structs"]["RRTMGPSolver"]["fields"])["radiation_method"] == "RM"
+
+
+def test_layer2_step_is_one_library_call_with_the_state_staged_once():
+    """update_fluxes!(s::HIPSpectralSolver) makes exactly one ccall — rrtmgp_hip_update_fluxes — keeps the reference's
+    validation and seeding steps (update_fluxes.jl:226-227), writes the presentation arrays the getters read, and hands
+    the nested descriptors over as addresses of the device's scratch slots (rooted by GC.@preserve)."""
+    (m,) = [x for x in _layer2_methods(_module()) if x.name.split(".")[-1] == "update_fluxes!"]
+    body = "".join(t.text for t in m.body if t.kind != "nl")
+    assert body.count("ccall(") == 1 and "(:rrtmgp_hip_update_fluxes,libhip[])" in body
+    assert "RRTMGP.check_values[]&&RRTMGP.validate_inputs(s)" in body and "RRTMGP._maybe_reset_rng_seed!(s.radiation_method,seedval)" in body
+    for need in ("presented_desc(s.presented_flux_lw,lw_band(lws),s.clear_flux_lw)", "presented_desc(s.presented_flux_sw,sws.band_flux,s.clear_flux_sw)",
+                 "ptr(s.net_flux_buffer),ptr(s.clear_net_flux_buffer)", "GC.@preservessc", "refptr(sc.prepare)"):
+        assert need in body, need
+    # ... and the separately callable steps never copy through the solvers' compute buffers
+    for x in _layer2_methods(_module()):
+        b = "".join(t.text for t in x.body if t.kind != "nl")
+        assert "update_presentation!" not in b and ".lws.flux" not in b and ".sws.flux" not in b, x.name
+
+
 # ---- the zero-allocation contract of the per-solve path (test/standalone.jl:361-383), held statically -----------------
 def _hot(src=JL):
     mod = _module(src)
     ref_names = {r["name"] for r in SIGS["methods"]}
     roots = [m for ms in _device_methods(mod).values() for m in ms if m.name.split(".")[-1] in ref_names]
     assert len(roots) >= 13, [m.name for m in roots]
+    roots += _layer2_methods(mod)       # the Layer-2 overrides are per-step code too (none in the round-2 fixture)
     return mod, JLITE.hot_methods(mod, roots)
 
 
@@ -295,6 +380,10 @@ def test_no_allocation_on_the_per_solve_path():
     names = {m.name.split(".")[-1] for m in hot}
     # the walk is not vacuous: it reaches the cache searches, the descriptors and the view conversion
     assert {"workspace", "lookup_handle", "state_desc", "flux_desc", "view2d", "opts", "check", "params_desc"} <= names, names
+    # ... and everything under the Layer-2 overrides
+    assert {"update_fluxes!", "update_lw_fluxes!", "update_sw_fluxes!", "update_net_fluxes!", "prepare_atmosphere!", "lw_solve!",
+            "sw_solve!", "presented_desc", "step_opts", "step_prepare", "prepare_desc", "add_into!", "set!", "refptr",
+            "cloud_lookups", "step_workspace"} <= names, names
     assert not any(n.endswith("_slow") for n in names)
     assert _allocations() == []
 
@@ -323,14 +412,17 @@ def test_strided_views_cross_the_abi_uncopied():
     and the extents travel with the call."""
     mod = _module()
     v = [m for m in mod.methods if m.name == "view2d"]
-    assert {JLITE.norm_type(m.params[0].type) for m in v} == {"StridedMatrix", "Nothing"}
+    assert {JLITE.norm_type(m.params[0].type) for m in v} == {"StridedMatrix", "Nothing", "AbstractMatrix"}
+    # anything without a (pointer, strides) form is refused with a message (a cold `_slow` function), never copied
+    fallback = next(m for m in v if JLITE.norm_type(m.params[0].type) == "AbstractMatrix")
+    assert "".join(t.text for t in fallback.body if t.kind != "nl") == "not_strided_slow(a)"
     body = {m.name.split(".")[-1]: "".join(t.text for t in m.body if t.kind != "nl") for m in mod.methods
             if m.name.split(".")[-1] in ("compute_col_gas!", "compute_relative_humidity!", "compute_gray_heating_rate!")
             and m.params and JLITE.norm_type(m.params[0].type) == "HIPDevice"}
     assert body["compute_col_gas!"].count("view2d(") == 3 and body["compute_relative_humidity!"].count("view2d(") == 4
     assert body["compute_gray_heating_rate!"].count("view2d(") == 3
     for b in body.values():
-        assert "ncol,nlay,view2d(" in b and "Array(" not in b and "copyto!" not in b
+        assert "ncol,nlay,set!(sc.v1,view2d(" in b and "Array(" not in b and "copyto!" not in b
 
 
 def test_device_owns_its_handles():
@@ -373,7 +465,7 @@ _STRUCT2JL = {"rrtmgp_gas_lookup_desc": "GasLookupDesc", "rrtmgp_cloud_lookup_de
               "rrtmgp_aerosol_lookup_desc": "AerosolLookupDesc", "rrtmgp_atmos_state": "AtmosStateDesc",
               "rrtmgp_lw_bcs": "LwBcsDesc", "rrtmgp_sw_bcs": "SwBcsDesc", "rrtmgp_flux_out": "FluxOutDesc",
               "rrtmgp_solve_opts": "SolveOpts", "rrtmgp_gray_state": "GrayStateDesc", "rrtmgp_params": "ParamsDesc",
-              "rrtmgp_prepare_opts": "PrepareOpts", "rrtmgp_view2d": "View2D"}
+              "rrtmgp_prepare_opts": "PrepareOpts", "rrtmgp_view2d": "View2D", "rrtmgp_update_fluxes_args": "UpdateFluxesArgs"}
 
 
 def test_ccall_argument_types_match_the_header():
@@ -417,10 +509,11 @@ def test_every_array_owner_used_in_a_ccall_is_gc_preserved():
     """`ptr(x)` / `pointer(x)` hand raw addresses to C: the object they came from must be rooted for the duration of the
     call (`GC.@preserve`).  For every device method, every parameter that carries arrays (by its annotation) and is named
     inside the ccall's argument list must also be named in the `GC.@preserve` that wraps that ccall."""
-    carriers = ("AbstractArray", "AtmosphericState", "GrayAtmosphericState", "LwBCs", "SwBCs", "FluxLW", "FluxSW")
+    carriers = ("AbstractArray", "AtmosphericState", "GrayAtmosphericState", "LwBCs", "SwBCs", "FluxLW", "FluxSW",
+                "HIPSpectralSolver")
     mod = _module()
     n = 0
-    for ms in _device_methods(mod).values():
+    for ms in list(_device_methods(mod).values()) + [_layer2_methods(mod)]:
         for m in ms:
             toks = [t for t in m.body if t.kind != "nl"]
             idx = [i for i, t in enumerate(toks) if t.kind == "id" and t.text == "ccall"]
@@ -472,7 +565,7 @@ def test_descriptor_constructors_pass_one_value_per_field():
             want = len(julia_fields(t.text))
             assert n == want, f"{t.text}(...) at line {t.line}: {n} arguments for {want} fields"
             n_calls += 1
-    assert n_calls >= 20, n_calls
+    assert n_calls >= 18, n_calls
 
 
 def test_descriptor_arguments_are_not_transposed():
@@ -494,7 +587,7 @@ def test_descriptor_arguments_are_not_transposed():
             # the last `.field` inside the argument, ignoring ternaries' C_NULL branches
             fields = []
             for k in range(len(a) - 1):
-                if a[k].kind == "id" and a[k].text in ("ptr", "pointer", "flux_ptr") and a[k + 1].text == "(":
+                if a[k].kind == "id" and a[k].text in ("ptr", "pointer", "flux_ptr", "refptr") and a[k + 1].text == "(":
                     inner = a[k + 2:JLITE._matching(a, k + 1)]
                     fields += [inner[q + 1].text for q in range(len(inner) - 1) if inner[q].text == "." and inner[q + 1].kind == "id"][-1:]
             if fields and fields[-1] in names:
@@ -503,3 +596,50 @@ def test_descriptor_arguments_are_not_transposed():
                 checked += 1
             pos += 1
     assert checked >= 45, checked
+
+
+# ---- what a Julia user needs to LOAD the extension: trigger package, Project patch, usage example --------------------
+def test_trigger_package_patch_and_example_are_consistent():
+    """julia/HIPRRTMGP (the weak dependency that triggers RRTMGPHIPExt, like CUDA triggers RRTMGPCUDAExt: reference
+    Project.toml:14-22), julia/Project.toml.patch and examples/julia_usage.jl: one uuid everywhere, the patch adds exactly
+    the weak dependency and the extension entry, and every name the example takes from the extension or from RRTMGP exists."""
+    proj = open(os.path.join(ROOT, "julia", "HIPRRTMGP", "Project.toml")).read()
+    uuid = re.search(r'^uuid = "([0-9a-f-]{36})"', proj, re.M).group(1)
+    assert re.search(r'^name = "HIPRRTMGP"', proj, re.M) and "<uuid>" not in proj
+    patch = open(os.path.join(ROOT, "julia", "Project.toml.patch")).read()
+    added = [ln[1:] for ln in patch.splitlines() if ln.startswith("+") and not ln.startswith("+++")]
+    assert added == [f'HIPRRTMGP = "{uuid}"', 'RRTMGPHIPExt = "HIPRRTMGP"'], added
+    assert not [ln for ln in patch.splitlines() if ln.startswith("-") and not ln.startswith("---")]
+    pkg = open(os.path.join(ROOT, "julia", "HIPRRTMGP", "src", "HIPRRTMGP.jl")).read()
+    assert 'Base.UUID("a01a1ee8-cea4-48fc-987c-fc7878d79da1"), "RRTMGP"' in pkg      # RRTMGP.jl's uuid (reference Project.toml:2)
+    assert "Base.get_extension(rr, :RRTMGPHIPExt)" in pkg and "const libpath" in pkg and 'ENV["RRTMGP_HIP_LIBRARY"]' in pkg
+    assert 'libhip[] = get(ENV, "RRTMGP_HIP_LIBRARY", libhip[])' in JL                # ... which the extension reads at load time
+    pm = JLITE.parse_module(pkg)
+    assert {m.name for m in pm.methods} >= {"extension", "__init__"} and "libpath" in pm.consts
+    ext_names = _module().names() | set(_module().exports)
+    for script in (os.path.join(ROOT, "examples", "julia_usage.jl"), os.path.join(ROOT, "julia", "test_hip_extension.jl")):
+        src = "\n".join(ln.split("#")[0] for ln in open(script).read().split("\n"))
+        toks = JLITE.tokenize(src)                                  # it tokenizes: balanced strings, no stray characters
+        assert sum(t.text == "(" for t in toks) == sum(t.text == ")" for t in toks)
+        for nm in re.findall(r"\bHIP\.([\w!]+)", src):
+            assert nm in ext_names, (script, nm)
+        for nm in re.findall(r"\bRRTMGP\.([\w!]+)", src):
+            assert nm in SIGS["modules"]["RRTMGP"], (script, nm)
+    ex = open(os.path.join(ROOT, "examples", "julia_usage.jl")).read()
+    for need in ("HIPRRTMGP.extension()", "HIP.HIPDevice(0)", "ClimaComms.SingletonCommsContext(device)", "RRTMGP.RRTMGPGridParams(FT; context",
+                 "HIP.pin!(solver)", "RRTMGP.update_fluxes!(solver)", "RRTMGP.net_flux(solver)"):
+        assert need in ex, need
+
+
+def test_pin_walk_is_bounded_and_unpin_parks_refused_arrays():
+    """`pin!` recursed through struct fields without a visited set (a cyclic object graph overflowed the stack)
+    and dropped the status of host_register / host_unregister.  Now: an IdSet of visited objects and a depth cap, a warning
+    on a refused registration, and an array whose unregistration the library refuses (a solve is still using the range)
+    is parked and retried instead of being forgotten."""
+    mod = _module()
+    by = {m.name: "".join(t.text for t in m.body if t.kind != "nl") for m in mod.methods}
+    assert "Base.IdSet{Any}()" in by["pin!"] and "max_depth" in by["pin!"]
+    w = by["pin_walk_slow"]
+    assert "xinseen||depth<0" in w and "push!(seen,x)" in w and "depth-1" in w and "@warn" in w and "finalizer(unpin_slow,x)" in w
+    assert "rc==0||push!(PARKED,a)" in by["unpin_slow"] and "retry_parked_slow()" in by["unpin_slow"]
+    assert "atexit(retry_parked_slow)" in by["__init__"]

@@ -419,7 +419,7 @@ BASE = {"ccall", "Ref", "Ptr", "Cvoid", "Cint", "Csize_t", "Int32", "Int64", "UI
         "PermutedDimsArray", "GC", "undef", "String", "Integer", "atexit", "values", "foreach", "empty!", "Symbol", "zeros",
         "min", "max", "first", "last", "vec", "Base", "Core", "convert", "ntuple", "all", "any", "isempty",
         "AbstractVector", "push!", "WeakRef", "collect", "eachindex", "isbitstype", "fieldnames", "getfield", "isstructtype",
-        "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray"}
+        "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray", "Module", "isdefined", "filter!", "in"}
 
 
 def _locals_of(m: Method) -> set:
@@ -536,7 +536,7 @@ def _type_structs(type_text: str, structs: dict) -> set:
     return {t.text for t in tokenize(type_text) if t.kind == "id" and t.text in structs}
 
 
-def bad_field_accesses(m: Method, structs: dict, hints: dict) -> List[Tuple[str, str, int]]:
+def bad_field_accesses(m: Method, structs: dict, hints: dict, aliases: dict = None) -> List[Tuple[str, str, int]]:
     """`x.f` / `x.f.g` chains in a method body whose base is a parameter (or a local assigned from such a chain) with a
     known struct type, naming a field the struct does not have.  `structs` = {name: {"fields": [[name, type]], ...}},
     `hints` = {(struct, field): [struct names]} for fields typed by an unbounded type parameter.
@@ -545,6 +545,9 @@ def bad_field_accesses(m: Method, structs: dict, hints: dict) -> List[Tuple[str,
     for p in list(m.params) + list(m.kwparams):
         if p.name and p.type:
             ts = _type_structs(p.type, structs)
+            for al, members in (aliases or {}).items():   # a type alias of the glue (`const HIPSpectralSolver = ...`)
+                if re.search(r"(?<![\w.])" + re.escape(al) + r"(?![\w])", p.type):
+                    ts |= set(members)
             if ts:
                 env[p.name] = ts
 
