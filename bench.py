@@ -99,6 +99,10 @@ def parse_args(argv=None):
                     help="strong: --ncol-total columns are split over the ranks in contiguous ranges (BASELINE config 4: "
                          "4096 columns on 1 -> 8 GPUs); weak (default): --ncol columns per rank")
     ap.add_argument("--ncol-total", type=int, default=4096, help="with --scaling strong: columns of the whole job")
+    ap.add_argument("--l2", choices=["off", "fused", "split"], default="off",
+                    help="time the Layer-2 step of a host model (update_fluxes! on HOST arrays: prepare_atmosphere! + LW + SW + net, "
+                         "AllSkyRadiation): `fused` = ONE call of rrtmgp_hip_update_fluxes (state staged once), `split` = the "
+                         "reference's four steps as separate calls (prepare, LW, SW staged separately; net sum on the host)")
     ap.add_argument("--no-legs", action="store_true", help="only the headline measurement (no variant / host / CPU legs)")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)   # child-process mode: compact JSON, no legs
     return ap.parse_args(argv)
@@ -132,8 +136,50 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def run_l2(args):
+    """The Layer-2 step on host arrays through the Python mirror of RRTMGPSolver (the Julia glue's update_fluxes! override
+    makes the same library call): columns/s and the bytes that crossed PCIe per column, from the workspace's counters."""
+    import rrtmgp_jl_amd  # noqa: F401
+    from rrtmgp_jl_amd import _lib, solver as L2, synthetic as S
+    from rrtmgp_jl_amd.states import TEST_PARAMETERS
+    _lib.require_gpu()
+    ft = np.float32 if args.dtype == "f32" else np.float64
+    ncol, nlay = args.ncol, args.nlay
+    lw, sw = S.make_gas_lookup("lw", ft), S.make_gas_lookup("sw", ft)
+    cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)
+    al = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft) if args.aerosols else None
+    asw = S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft) if args.aerosols else None
+    as_, lb, sb = S.make_columns(ncol, nlay, ft, seed=2026, clouds=True, cld_frac=args.cld_frac, aerosols=args.aerosols,
+                                 cos_zenith=0.86)
+    diag = args.clear_sky_diag != "off"
+    method = (L2.AllSkyRadiationWithClearSkyDiagnostics if diag else L2.AllSkyRadiation)(aerosol_radiation=args.aerosols)
+    s = L2.RRTMGPSolver(method, TEST_PARAMETERS, lb, sb, as_, lookups=L2.LookupBundle(lw, sw, cl, cs, al, asw),
+                        fused=args.l2 == "fused")
+    for _ in range(args.warmup):
+        L2.update_fluxes(s)
+    b0 = s.lws.ws.transfer_bytes()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        L2.update_fluxes(s)
+        ms.append(1e3 * (time.perf_counter() - ts))
+    elapsed = time.perf_counter() - t0
+    b1 = s.lws.ws.transfer_bytes()
+    assert np.isfinite(L2.net_flux(s)).all() and (L2.lw_flux_up(s)[0] > 0).all()
+    rec = {"value": ncol * args.steps / elapsed, "unit": "columns/s", "ms_per_step": 1e3 * elapsed / args.steps,
+           "min_ms": min(ms), "median_ms": statistics.median(ms), "ncol": ncol, "dtype": args.dtype,
+           "h2d_bytes_per_column": (b1[0] - b0[0]) / (ncol * args.steps), "d2h_bytes_per_column": (b1[1] - b0[1]) / (ncol * args.steps),
+           "calls_per_step": 1 if args.l2 == "fused" else 3,
+           "workload": f"update_fluxes! on HOST arrays ({args.l2}): prepare_atmosphere! (clip + col_dry) + LW + SW two-stream + net, "
+                       f"{'AllSkyRadiationWithClearSkyDiagnostics' if diag else 'AllSkyRadiation'}, {ncol} x {nlay}"}
+    print(json.dumps(rec))
+
+
 def main():
     args = parse_args()
+    if args.l2 != "off":
+        return run_l2(args)
     import torch
     import rrtmgp_jl_amd  # noqa: F401
     from rrtmgp_jl_amd import _lib, rte, synthetic as S
@@ -405,6 +451,12 @@ def main():
             out["host_end_to_end"] = run_leg("host", ["--host"])
             out["host_end_to_end"]["note"] = ("same workload, HOST arrays staged H2D/D2H inside each solve (page-locked once, "
                                               "chunked pipeline); never `value`")
+            # what a HOST model (the Julia drop-in with array_type = Array) pays per radiation step: the Layer-2 step as one
+            # library call, next to the reference's four steps as separate calls
+            out["l2_update_fluxes_host"] = {"fused": run_leg("l2_fused", ["--l2", "fused"]),
+                                            "split": run_leg("l2_split", ["--l2", "split"]),
+                                            "fused_clear_sky_diag": run_leg("l2_fused_diag", ["--l2", "fused", "--clear-sky-diag", "one-pass"]),
+                                            "note": "update_fluxes!(solver) from host arrays, PCIe inclusive; never `value`"}
             precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
             out["precise_f32"] = (run_leg("precise_f32", [], env={"RRTMGP_HIP_LIBRARY": precise}) if os.path.exists(precise)
                                   else {"error": "libhip_rrtmgp_precise.so not built (make -C rrtmgp.jl_amd/csrc precise)"})

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 #include "device.h"
@@ -1016,15 +1017,33 @@ static int run_column_pipeline(rrtmgp_workspace *ws, size_t ncol, size_t E, bool
     // chunk size: small enough that the first upload and the last download (the only copies nothing overlaps) are a
     // small share, large enough that every chunk still fills the persistent grid several times over
     static const size_t per_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 8192;
-    const int nchunk = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
+    const int nfull = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
+    const size_t per = (ncol + nfull - 1) / nfull;  // the full chunk: equal chunks, staging buffers never grow past it
+    // Nothing overlaps the first chunk's upload and the last chunk's download, so the pipeline is ramped: the first full
+    // chunk is cut into 1/4 + 1/4 + 1/2 and the last one into 1/2 + 1/4 + 1/4 (the exposed copies shrink 4x; measured on the
+    // Layer-2 step of 131 072 columns: tools/experiments/README.md, round 4).  RRTMGP_HIP_HOST_NO_RAMP=1: equal chunks.
+    static const bool no_ramp = getenv("RRTMGP_HIP_HOST_NO_RAMP") != nullptr;
+    std::vector<size_t> edge{0};
+    {
+        const bool ramp = !no_ramp && nfull >= 4 && per >= 4096;
+        for (int c = 0; c < nfull; c++) {
+            const size_t lo = std::min(ncol, per * c), hi = std::min(ncol, per * (c + 1));
+            if (hi == lo) break;
+            if (ramp && c == 0) { edge.push_back(lo + (hi - lo) / 4); edge.push_back(lo + (hi - lo) / 2); }
+            if (ramp && c == nfull - 1) { edge.push_back(lo + (hi - lo) / 2); edge.push_back(lo + 3 * (hi - lo) / 4); }
+            edge.push_back(hi);
+        }
+    }
+    const int nchunk = (int)edge.size() - 1;
     RR_HIP(hipStreamSynchronize(ws->stream));  // earlier work of the caller on this workspace
     Stager prev{ws, {}};
     prev.cs = ws->copy_stream;
     int rc = RRTMGP_OK;
+    // (the staging buffers grow to the full chunk's size during the first call only — hipFree waits for the device, so a
+    // buffer is never released under a copy in flight — and stay there: warm calls allocate nothing)
     for (int c = 0; c < nchunk && rc == RRTMGP_OK; c++) {
-        const size_t per = (ncol + nchunk - 1) / nchunk;  // equal chunks, the last one shorter: staging buffers never grow mid-way
-        const size_t c0 = std::min(ncol, per * c), c1 = std::min(ncol, per * (c + 1));
-        if (c1 == c0) break;
+        const size_t c0 = edge[c], c1 = edge[c + 1];
+        if (c1 == c0) continue;
         ColumnSlice sl{E, c0};
         std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
         Stager st{ws, {}};
@@ -1263,83 +1282,150 @@ static int solve_gray_sw_t(rrtmgp_workspace *ws, int twostream, const rrtmgp_gra
 }
 
 // ---- 2-D view arguments (rrtmgp_view2d) of compute_col_gas! / compute_relative_humidity! / compute_gray_heating_rate! ----
-// The reference passes strided views (rows of layerdata, a row of Vmr.vmr, domain views of level arrays).  Device views
-// are used in place.  A host view is staged as the memory span it covers; views whose spans overlap (rows of ONE parent
-// array) share one staging buffer and one upload; a span that is written is staged in AND out unless the written view is
-// dense and alone in it, so whatever else lives in the span comes back as it went in.
+// The reference passes strided views (rows of layerdata: element stride 4; a row of Vmr.vmr: element stride ngas; domain
+// views of level arrays: column stride = rows of the parent).  Device views are used in place.  A host view moves exactly
+// its own elements, once, and reaches the kernel as a dense (n0, n1) array:
+//   * dense                                  -> one copy;
+//   * unit stride0, padded columns           -> one 2-D DMA (rows of n0 elements, stride1 apart), when a row is >= 64 bytes;
+//   * anything else (stride0 > 1, C order)   -> gathered by the CPU into the workspace's page-locked bounce buffer (a few
+//     threads for large arrays), one DMA; written views come back the same way and are scattered into place.
+// Round 3 staged the memory SPAN of a strided view in and out instead (4x the bytes for a row of layerdata, and — with a
+// sharded workspace and column-fastest views — overlapping spans that the shards' write-backs raced on).
 struct ViewArg {
     const rrtmgp_view2d *v;
     size_t n0, n1;
     bool out;
-    char *dev = nullptr;  // device address of element (0, 0)
-    const char *lo() const { return (const char *)v->ptr; }
-    size_t span(size_t E) const { return ((n0 - 1) * (size_t)v->stride0 + (n1 - 1) * (size_t)v->stride1 + 1) * E; }
+    char *dev = nullptr;          // device address of element (0, 0)
+    int64_t ds0 = 0, ds1 = 0;     // element strides of the array the kernel sees
+    size_t pack_off = ~size_t(0); // offset in the bounce buffer when the view is gathered / scattered by the CPU
     bool dense() const { return v->stride0 == 1 && (size_t)v->stride1 == n0; }
 };
-static int stage_views(Stager &st, int mem, ViewArg *a, int n, size_t E) {
+template <typename T>
+static void strided_copy_t(T *dense, T *strided, size_t n0, size_t n1, size_t s0, size_t s1, bool to_dense, size_t j0, size_t j1) {
+    for (size_t j = j0; j < j1; j++) {
+        T *d = dense + j * n0, *q = strided + j * s1;
+        if (to_dense) for (size_t i = 0; i < n0; i++) d[i] = q[i * s0];
+        else for (size_t i = 0; i < n0; i++) q[i * s0] = d[i];
+    }
+}
+static void strided_copy(void *dense, void *strided, size_t n0, size_t n1, size_t s0, size_t s1, size_t E, bool to_dense) {
+    auto part = [&](size_t j0, size_t j1) {
+        if (E == 4) strided_copy_t<uint32_t>((uint32_t *)dense, (uint32_t *)strided, n0, n1, s0, s1, to_dense, j0, j1);
+        else strided_copy_t<uint64_t>((uint64_t *)dense, (uint64_t *)strided, n0, n1, s0, s1, to_dense, j0, j1);
+    };
+    // columns are disjoint in both layouts whenever the view itself does not alias (Julia views, numpy basic slices)
+    const size_t nthr = n0 * n1 >= (size_t(1) << 20) ? std::min<size_t>(4, n1) : 1;
+    if (nthr <= 1) { part(0, n1); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nthr; t++) th.emplace_back(part, n1 * t / nthr, n1 * (t + 1) / nthr);
+    part(0, n1 / nthr);
+    for (auto &x : th) x.join();
+}
+struct ViewPack {   // the CPU-gathered views of one call
+    rrtmgp_workspace *ws;
+    ViewArg *a = nullptr;
+    int n = 0;
+    size_t E = 0, in_hi = 0, out_lo = ~size_t(0), out_hi = 0;
+    // after the kernel: the written views' dense images come home in one DMA and are scattered into the caller's arrays
+    int finish() {
+        if (out_hi <= out_lo) return RRTMGP_OK;
+        RR_HIP(hipMemcpyAsync(ws->bounce_h + out_lo, ws->bounce_d + out_lo, out_hi - out_lo, hipMemcpyDeviceToHost, ws->stream));
+        ws->d2h_bytes += out_hi - out_lo;
+        RR_HIP(hipStreamSynchronize(ws->stream));
+        for (int i = 0; i < n; i++)
+            if (a[i].v && a[i].out && a[i].pack_off != ~size_t(0))
+                strided_copy(ws->bounce_h + a[i].pack_off, a[i].v->ptr, a[i].n0, a[i].n1, (size_t)a[i].v->stride0, (size_t)a[i].v->stride1, E, false);
+        return RRTMGP_OK;
+    }
+};
+static int stage_views(Stager &st, ViewPack &vp, int mem, ViewArg *a, int n, size_t E) {
     static const int slots[4] = {S_PLEV, S_PLAY, S_TLAY, S_AUX0};
+    RR_CHECK(n <= 4, "internal: too many view arguments");
+    vp.a = a; vp.n = n; vp.E = E;
+    size_t pack = 0;
+    for (int pass = 0; pass < 2; pass++)   // gathered inputs first, then the written views: the one upload covers inputs only
+        for (int i = 0; i < n; i++) {
+            if (!a[i].v || (pass == 1) != a[i].out) continue;
+            RR_CHECK(a[i].v->ptr && a[i].v->stride0 >= 1 && a[i].v->stride1 >= 1, "view2d: null pointer or non-positive stride");
+            a[i].ds0 = a[i].v->stride0; a[i].ds1 = a[i].v->stride1;
+            if (mem == RRTMGP_MEM_DEVICE) { a[i].dev = (char *)a[i].v->ptr; continue; }
+            a[i].ds0 = 1; a[i].ds1 = (int64_t)a[i].n0;   // every host view reaches the kernel dense
+            const bool rows2d = a[i].v->stride0 == 1 && (size_t)a[i].v->stride1 > a[i].n0 && a[i].n0 * E >= 64;
+            if (!a[i].dense() && !rows2d) { a[i].pack_off = pack; pack += Stager::al(a[i].n0 * a[i].n1 * E); }
+        }
+    if (mem == RRTMGP_MEM_DEVICE) return RRTMGP_OK;
+    if (pack) TRY(bounce_ensure(st.ws, pack));
     for (int i = 0; i < n; i++) {
         if (!a[i].v) continue;
-        RR_CHECK(a[i].v->ptr && a[i].v->stride0 >= 1 && a[i].v->stride1 >= 1, "view2d: null pointer or non-positive stride");
-        if (mem == RRTMGP_MEM_DEVICE) a[i].dev = (char *)a[i].v->ptr;
-    }
-    if (mem == RRTMGP_MEM_DEVICE) return RRTMGP_OK;
-    RR_CHECK(n <= 4, "internal: too many view arguments");
-    int order[4], m = 0;
-    for (int i = 0; i < n; i++) if (a[i].v) order[m++] = i;
-    std::sort(order, order + m, [&](int x, int y) { return std::less<const char *>()(a[x].lo(), a[y].lo()); });
-    for (int i = 0, g = 0; i < m; g++) {
-        const char *lo = a[order[i]].lo(), *hi = lo + a[order[i]].span(E);
-        int j = i + 1;
-        while (j < m && a[order[j]].lo() < hi) { hi = std::max(hi, a[order[j]].lo() + a[order[j]].span(E)); j++; }
-        bool any_out = false;
-        for (int t = i; t < j; t++) any_out = any_out || a[order[t]].out;
+        const size_t bytes = a[i].n0 * a[i].n1 * E, width = a[i].n0 * E, pitch = (size_t)a[i].v->stride1 * E;
         void *dev = nullptr;
-        if (!any_out) TRY(st.in(mem, slots[g], lo, (size_t)(hi - lo), (const void **)&dev));
-        else if (j == i + 1 && a[order[i]].dense()) TRY(st.out(mem, slots[g], const_cast<char *>(lo), (size_t)(hi - lo), &dev));
-        else TRY(st.inout(mem, slots[g], lo, (size_t)(hi - lo), &dev));
-        for (int t = i; t < j; t++) a[order[t]].dev = (char *)dev + (a[order[t]].lo() - lo);
-        i = j;
+        if (a[i].pack_off != ~size_t(0)) {
+            dev = st.ws->bounce_d + a[i].pack_off;
+            if (!a[i].out) {
+                strided_copy(st.ws->bounce_h + a[i].pack_off, a[i].v->ptr, a[i].n0, a[i].n1, (size_t)a[i].v->stride0, (size_t)a[i].v->stride1, E, true);
+                vp.in_hi = std::max(vp.in_hi, a[i].pack_off + bytes);
+            } else {
+                vp.out_lo = std::min(vp.out_lo, a[i].pack_off);
+                vp.out_hi = std::max(vp.out_hi, a[i].pack_off + bytes);
+            }
+        } else if (a[i].dense()) {
+            if (a[i].out) TRY(st.out(mem, slots[i], a[i].v->ptr, bytes, &dev));
+            else TRY(st.in(mem, slots[i], a[i].v->ptr, bytes, (const void **)&dev));
+        } else {   // unit stride0, padded columns: n1 rows of n0 elements
+            if (a[i].out) TRY(st.out2d(slots[i], a[i].v->ptr, width, a[i].n1, pitch, &dev));
+            else TRY(st.in2d(slots[i], a[i].v->ptr, width, a[i].n1, pitch, (const void **)&dev));
+        }
+        a[i].dev = (char *)dev;
+    }
+    if (vp.in_hi) {   // the gathered inputs: one DMA
+        RR_HIP(hipMemcpyAsync(st.ws->bounce_d, st.ws->bounce_h, vp.in_hi, hipMemcpyHostToDevice, st.ws->stream));
+        st.ws->h2d_bytes += vp.in_hi;
     }
     return RRTMGP_OK;
 }
 template <typename T>
 static View2<T> dev_view(const ViewArg &a) {
-    return a.v ? View2<T>{(T *)a.dev, a.v->stride0, a.v->stride1} : View2<T>{nullptr, 0, 0};
+    return a.v ? View2<T>{(T *)a.dev, a.ds0, a.ds1} : View2<T>{nullptr, 0, 0};
 }
 
 template <typename FT>
 static int col_gas_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *p_lev,
                      const rrtmgp_view2d *col_dry, const rrtmgp_params *ps, const rrtmgp_view2d *vmr_h2o, const void *lat) {
     Stager st{ws, {}};
+    ViewPack vp{ws};
     ViewArg a[3] = {{p_lev, nlay + 1, ncol, false}, {col_dry, nlay, ncol, true}, {vmr_h2o, nlay, ncol, false}};
-    TRY(stage_views(st, mem, a, 3, sizeof(FT)));
+    TRY(stage_views(st, vp, mem, a, 3, sizeof(FT)));
     const FT *la;
     TRY(st.in(mem, S_LAT, lat, ncol * sizeof(FT), (const void **)&la));
     TRY(launch_col_gas<FT>(ws, (int)ncol, (int)nlay, dev_view<const FT>(a[0]), dev_view<FT>(a[1]), *ps, dev_view<const FT>(a[2]), la));
-    return st.finish();
+    TRY(st.finish());
+    return vp.finish();
 }
 
 template <typename FT>
 static int rel_hum_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *rh,
                      const rrtmgp_view2d *p_lay, const rrtmgp_view2d *t_lay, const rrtmgp_params *ps, const rrtmgp_view2d *vmr_h2o) {
     Stager st{ws, {}};
+    ViewPack vp{ws};
     ViewArg a[4] = {{rh, nlay, ncol, true}, {p_lay, nlay, ncol, false}, {t_lay, nlay, ncol, false}, {vmr_h2o, nlay, ncol, false}};
-    TRY(stage_views(st, mem, a, 4, sizeof(FT)));
+    TRY(stage_views(st, vp, mem, a, 4, sizeof(FT)));
     TRY(launch_rel_hum<FT>(ws, (int)ncol, (int)nlay, dev_view<FT>(a[0]), dev_view<const FT>(a[1]), dev_view<const FT>(a[2]), *ps,
                            dev_view<const FT>(a[3])));
-    return st.finish();
+    TRY(st.finish());
+    return vp.finish();
 }
 
 template <typename FT>
 static int heating_rate_t(rrtmgp_workspace *ws, int32_t mem, size_t ncol, size_t nlay, const rrtmgp_view2d *hr_lay,
                           const rrtmgp_view2d *p_lev, const rrtmgp_view2d *flux_net, double cp_d, double grav) {
     Stager st{ws, {}};
+    ViewPack vp{ws};
     ViewArg a[3] = {{hr_lay, nlay, ncol, true}, {p_lev, nlay + 1, ncol, false}, {flux_net, nlay + 1, ncol, false}};
-    TRY(stage_views(st, mem, a, 3, sizeof(FT)));
+    TRY(stage_views(st, vp, mem, a, 3, sizeof(FT)));
     TRY(launch_heating_rate<FT>(ws, (int)ncol, (int)nlay, dev_view<FT>(a[0]), dev_view<const FT>(a[2]), dev_view<const FT>(a[1]),
                                 grav, cp_d));
-    return st.finish();
+    TRY(st.finish());
+    return vp.finish();
 }
 
 

@@ -111,6 +111,9 @@ template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT
 // ~745 gives exactly (0, 1) like libm.  RR_PRECISE_F32 builds keep libm.
 // (1 - e^-r) for |r| <= ln2 / 2, and the reduction x = n ln2 + r of a non-negative x
 __device__ __forceinline__ double exp_reduce(double x, int &ni) {
+    // an overflowed optical depth (+inf, or beyond 2^52 ln 2 where the reduction loses r) must saturate to an opaque layer,
+    // (0, 1), as libm does, not turn into NaN: everything from 1500 on gives exactly that (2^-2000 underflows to 0)
+    x = __builtin_fmin(x, 1500.0);
     const double n = __builtin_rint(x * 1.4426950408889634074);   // x / ln 2
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);  // ln2_hi (the low 21 bits are zero: n * ln2_hi is exact)
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);         // ln2_lo

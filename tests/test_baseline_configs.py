@@ -78,9 +78,21 @@ def test_config2_full_vmr_overcast_vs_float64_oracle(tables32, tables64):
     # be as close to the Float64 reference as the reference's own Float32 arithmetic is, and within the F32 <-> F32
     # budget of that Float32 run.
     cpu32 = O.solve_sw(S.make_columns(128, 64, np.float32, **kw)[0], sb32, tables32["sw"], tables32["cld_sw"], seed=7)
-    inherent = _maxdiff(cpu32, ref_sw, SWN)
-    assert _maxdiff(sw, ref_sw, SWN) < max(1.2e-1, 1.05 * inherent + 2e-2), (inherent, _maxdiff(sw, ref_sw, SWN))
-    assert _maxdiff(sw, cpu32, SWN) < 2e-2
+    assert _maxdiff(sw, cpu32, SWN) < 2e-2                       # F32 <-> F32: the device against the reference arithmetic
+    # F32 <-> F64, column by column: the reference's fixed 1.2e-1 FIRST.  A column may exceed it only where the reference
+    # algorithm in Float32 on the CPU exceeds it too (its inherent Float32 error there), and then by no more than that
+    # error + the F32 <-> F32 budget; such columns are named, so a regression cannot hide behind the oracle's own error.
+    def per_column(a, b):
+        return np.max([np.abs(np.float64(getattr(a, n)) - np.float64(getattr(b, n))).max(axis=0) for n in SWN], axis=0)
+    dev, inherent = per_column(sw, ref_sw), per_column(cpu32, ref_sw)
+    over = np.flatnonzero(dev >= 1.2e-1)
+    assert np.all(inherent[over] >= 1.2e-1), ("columns beyond the reference ratchet where the CPU Float32 run is inside it",
+                                             over[inherent[over] < 1.2e-1], dev[over], inherent[over])
+    assert np.all(dev[over] <= inherent[over] + 2e-2), (over, dev[over], inherent[over])
+    assert len(over) <= 2, (over, dev[over], inherent[over])      # today: one nearly conservative cloud layer in one column
+    if len(over):
+        print(f"note: column(s) {over.tolist()} exceed the 1.2e-1 ratchet in Float32 on the CPU as well: "
+              f"device {dev[over]}, CPU Float32 {inherent[over]} W/m2 from Float64")
     np.testing.assert_array_equal(as32.cloud_state.cld_cover_lw, as64.cloud_state.cld_cover_lw.astype(np.float32))
     np.testing.assert_array_equal(as32.cloud_state.cld_cover_sw, as64.cloud_state.cld_cover_sw.astype(np.float32))
 
@@ -151,12 +163,22 @@ def test_config3_allsky_aerosols_4096x73_sharded(tables32):
         f = rte.solve_sw(rte.TwoStreamSWRTE(hi - lo, nlay, np.float32, b_sw), a, t["sw"], t["cld_sw"], t["aero_sw"], seed=5,
                          col_offset=lo)
         np.testing.assert_array_equal(f.flux_dn_dir, whole_sw.flux_dn_dir[:, lo:hi])
-    # oracle on a strided sample
-    idx = slice(0, ncol, 97)
-    sub_as, sub_lb = sharding.shard_container(as_, 0, 1, ncol), sharding.shard_container(lb, 0, 1, ncol)
-    ref = O.solve_lw(sub_as, sub_lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=5)
-    assert np.abs(ref.flux_up[:, 0] - whole_lw.flux_up[:, 0]).max() < 1e-3
-    assert np.all(np.isfinite(whole_sw.flux_net[:, idx]))
+    # oracle on a strided sample: every flux of 16 columns (the generator is keyed by the global column, so a one-column
+    # state with col_offset = g is column g of the big one)
+    kw = dict(seed=3, aerosols=True, night_fraction=0.1)
+    worst_lw = worst_sw = 0.0
+    for g in range(11, ncol, 256):
+        a1, l1, s1 = S.make_columns(1, nlay, np.float32, col_offset=g, **kw)
+        r_lw = O.solve_lw(a1, l1, t["lw"], t["cld_lw"], t["aero_lw"], seed=5, col_offset=g)
+        r_sw = O.solve_sw(a1, s1, t["sw"], t["cld_sw"], t["aero_sw"], seed=5, col_offset=g)
+        for n in LWN:
+            worst_lw = max(worst_lw, float(np.abs(np.float64(getattr(r_lw, n)[:, 0]) - np.float64(getattr(whole_lw, n)[:, g])).max()))
+        for n in SWN:
+            worst_sw = max(worst_sw, float(np.abs(np.float64(getattr(r_sw, n)[:, 0]) - np.float64(getattr(whole_sw, n)[:, g])).max()))
+    assert worst_lw < 1e-3 and worst_sw < 2e-2, (worst_lw, worst_sw)
+    for f, names in ((whole_lw, LWN), (whole_sw, SWN)):
+        for n in names:
+            assert np.all(np.isfinite(getattr(f, n)))
 
 
 def test_config4_gcm_scale_shard_of_1m_columns(tables32):

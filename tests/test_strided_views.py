@@ -188,3 +188,80 @@ def test_solver_getters_are_domain_views_and_heating_rate_uses_them(tables64):
     assert hr.shape == (nlay - 1, ncol)
     np.testing.assert_allclose(hr, TEST_PARAMETERS.grav * (nf[1:] - nf[:-1]) / (p[1:] - p[:-1]) / TEST_PARAMETERS.cp_d,
                                rtol=1e-12)
+
+
+def test_a_strided_view_moves_its_own_elements_once():
+    """a written view with stride0 > 1 used to be staged as the memory span it covers, in AND out — for
+    `compute_col_gas!` on `view(layerdata, 1, :, :)` the whole (4, nlay, ncol) array both ways.  Now every host view moves
+    exactly its elements: counted by the stager, <= 1.1x the algorithmic bytes (the 256-byte alignment of the pieces)."""
+    params = RRTMGPParameters()
+    ft = np.float32
+    as_ = _state(ft, ncol=4096, nlay=64)
+    nlay, ncol = as_.dims
+    ws = rte.Workspace(ncol, nlay, ft)
+    ld, vmr = as_.layerdata, as_.vmr.vmr
+    before = ld.copy(order="F")
+    want = O.compute_col_gas(as_.p_lev, params, np.asfortranarray(vmr[0]), as_.lat)
+    rte.compute_col_gas(ws, as_.p_lev, params, vmr[0], as_.lat, out=ld[0])          # warm: buffers
+    u0, d0 = ws.transfer_bytes()
+    ld[0] = -1.0
+    rte.compute_col_gas(ws, as_.p_lev, params, vmr[0], as_.lat, out=ld[0])
+    u1, d1 = ws.transfer_bytes()
+    np.testing.assert_allclose(ld[0], want, rtol=1e-5)
+    np.testing.assert_array_equal(ld[1:], before[1:])
+    E = 4
+    up_alg = (nlay + 1) * ncol * E + nlay * ncol * E + ncol * E        # p_lev + vmr_h2o + lat
+    dn_alg = nlay * ncol * E                                           # col_dry
+    assert up_alg <= u1 - u0 <= 1.1 * up_alg, (u1 - u0, up_alg)
+    assert dn_alg <= d1 - d0 <= 1.1 * dn_alg, (d1 - d0, dn_alg)
+    # relative humidity on three rows of ONE parent: each row once, not the parent three times
+    h2o = np.asfortranarray(vmr[0])
+    rte.compute_relative_humidity(ws, ld[1], ld[2], params, h2o, out=ld[3])
+    u2, d2 = ws.transfer_bytes()
+    rte.compute_relative_humidity(ws, ld[1], ld[2], params, h2o, out=ld[3])
+    u3, d3 = ws.transfer_bytes()
+    assert u3 - u2 <= 1.1 * 3 * nlay * ncol * E and d3 - d2 <= 1.1 * nlay * ncol * E
+
+
+@pytest.mark.parametrize("device", [0, [0, 0, 0]])
+def test_column_fastest_views_on_a_sharded_workspace(device):
+    """C-order numpy (nlay, ncol) arrays are views with stride1 < stride0.  On a multi-shard workspace
+    their column ranges' memory spans overlap almost entirely; round 3 staged each shard's whole span in and out, and
+    the concurrent write-backs overwrote other shards' fresh columns with stale data.  Every shard now moves only its own
+    elements."""
+    params = RRTMGPParameters()
+    ft = np.float64
+    as_ = _state(ft, ncol=41, nlay=23, full_vmr=False)
+    nlay, ncol = as_.dims
+    ws = rte.Workspace(ncol, nlay, ft, device)
+    p_lev_c = np.ascontiguousarray(as_.p_lev)                  # C order: stride0 = ncol, stride1 = 1
+    h2o_c = np.ascontiguousarray(as_.vmr.vmr_h2o)
+    out_c = np.full((nlay, ncol), -1.0, order="C")
+    assert p_lev_c.strides == (ncol * 8, 8)
+    want = O.compute_col_gas(as_.p_lev, params, as_.vmr.vmr_h2o, as_.lat)
+    for _ in range(5):                                         # the old failure was a race: give it chances
+        out_c[:] = -1.0
+        rte.compute_col_gas(ws, p_lev_c, params, h2o_c, as_.lat, out=out_c)
+        np.testing.assert_allclose(out_c, want, rtol=1e-13)
+    rh_c = np.full((nlay, ncol), -1.0, order="C")
+    p_c, t_c = np.ascontiguousarray(as_.layerdata[1]), np.ascontiguousarray(as_.layerdata[2])
+    rte.compute_relative_humidity(ws, p_c, t_c, params, h2o_c, out=rh_c)
+    np.testing.assert_allclose(rh_c, O.compute_relative_humidity(np.asfortranarray(p_c), np.asfortranarray(t_c), params, as_.vmr.vmr_h2o),
+                               rtol=1e-12)
+
+
+def test_large_strided_views_are_gathered_by_several_threads():
+    """From 2^20 elements on the CPU gather / scatter of a strided view is split over a few threads (disjoint column ranges)."""
+    params = RRTMGPParameters()
+    ft = np.float32
+    ncol, nlay = 20000, 64
+    rng = np.random.default_rng(0)
+    ld = np.asfortranarray(rng.uniform(1.0, 2.0, (4, nlay, ncol)).astype(ft))
+    p_lev = np.asfortranarray(np.linspace(1.0e5, 1.0e3, nlay + 1, dtype=ft)[:, None] * np.ones((1, ncol), dtype=ft))
+    h2o3 = np.asfortranarray(rng.uniform(0.0, 0.02, (3, nlay, ncol)).astype(ft))
+    before = ld.copy(order="F")
+    ws = rte.Workspace(ncol, nlay, ft)
+    rte.compute_col_gas(ws, p_lev, params, h2o3[1], None, out=ld[0])
+    want = O.compute_col_gas(p_lev, params, np.asfortranarray(h2o3[1]), None)
+    np.testing.assert_allclose(ld[0], want, rtol=1e-5)
+    np.testing.assert_array_equal(ld[1:], before[1:])

@@ -218,7 +218,7 @@ def test_fused_step_through_the_column_pipeline(tables32):
         sum(getattr(a.cloud_state, n).nbytes for n in ("cld_r_eff_liq", "cld_r_eff_ice", "cld_path_liq", "cld_path_ice", "cld_frac"))
     bcs = f.lws.bcs.sfc_emis.nbytes + sum(getattr(f.sws.bcs, n).nbytes for n in ("cos_zenith", "toa_flux", "sfc_alb_direct", "sfc_alb_diffuse"))
     assert state + bcs <= f_up <= state + bcs + 64 * a.vmr.vmr.nbytes   # (+ the well-mixed vector, once per staging set)
-    assert u_up > 2.5 * f_up, (u_up, f_up)   # prepare + LW + SW each stage the state
+    assert u_up > 1.9 * f_up, (u_up, f_up)   # prepare, LW and SW each stage (their part of) the state
     assert f_dn < u_dn
 
 
