@@ -1017,33 +1017,18 @@ static int run_column_pipeline(rrtmgp_workspace *ws, size_t ncol, size_t E, bool
     // chunk size: small enough that the first upload and the last download (the only copies nothing overlaps) are a
     // small share, large enough that every chunk still fills the persistent grid several times over
     static const size_t per_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 8192;
-    const int nfull = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
-    const size_t per = (ncol + nfull - 1) / nfull;  // the full chunk: equal chunks, staging buffers never grow past it
-    // Nothing overlaps the first chunk's upload and the last chunk's download, so the pipeline is ramped: the first full
-    // chunk is cut into 1/4 + 1/4 + 1/2 and the last one into 1/2 + 1/4 + 1/4 (the exposed copies shrink 4x; measured on the
-    // Layer-2 step of 131 072 columns: tools/experiments/README.md, round 4).  RRTMGP_HIP_HOST_NO_RAMP=1: equal chunks.
-    static const bool no_ramp = getenv("RRTMGP_HIP_HOST_NO_RAMP") != nullptr;
-    std::vector<size_t> edge{0};
-    {
-        const bool ramp = !no_ramp && nfull >= 4 && per >= 4096;
-        for (int c = 0; c < nfull; c++) {
-            const size_t lo = std::min(ncol, per * c), hi = std::min(ncol, per * (c + 1));
-            if (hi == lo) break;
-            if (ramp && c == 0) { edge.push_back(lo + (hi - lo) / 4); edge.push_back(lo + (hi - lo) / 2); }
-            if (ramp && c == nfull - 1) { edge.push_back(lo + (hi - lo) / 2); edge.push_back(lo + 3 * (hi - lo) / 4); }
-            edge.push_back(hi);
-        }
-    }
-    const int nchunk = (int)edge.size() - 1;
+    const int nchunk = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
+    // (equal chunks.  A ramped pipeline — first and last chunk cut into quarters so that the only copies nothing overlaps
+    // shrink — was measured on the Layer-2 step and is slower, 38.6 vs 38.3 ms: what a chunked step loses against two big
+    // launches is the tail of the persistent grid at the end of every launch, not the exposed copies; tools/experiments/README.md)
     RR_HIP(hipStreamSynchronize(ws->stream));  // earlier work of the caller on this workspace
     Stager prev{ws, {}};
     prev.cs = ws->copy_stream;
     int rc = RRTMGP_OK;
-    // (the staging buffers grow to the full chunk's size during the first call only — hipFree waits for the device, so a
-    // buffer is never released under a copy in flight — and stay there: warm calls allocate nothing)
     for (int c = 0; c < nchunk && rc == RRTMGP_OK; c++) {
-        const size_t c0 = edge[c], c1 = edge[c + 1];
-        if (c1 == c0) continue;
+        const size_t per = (ncol + nchunk - 1) / nchunk;  // equal chunks, the last one shorter: staging buffers never grow mid-way
+        const size_t c0 = std::min(ncol, per * c), c1 = std::min(ncol, per * (c + 1));
+        if (c1 == c0) break;
         ColumnSlice sl{E, c0};
         std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
         Stager st{ws, {}};
