@@ -190,8 +190,12 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                     if (DIAG) { acc[nlay * NA + 5] = s; acc[nlay * NA + 4] = FT(0); }
                 }
             }
+            // DIAG: above the highest cloudy layer of the COLUMN (wave-uniform; every layer of a cloudless column) the clear-sky
+            // stream IS the all-sky stream — same optics, same beam, nothing reflected from above: no arithmetic of its own,
+            // no scratch rows (the second sweep reads the all-sky rows for both); `also_twin`: its sums go to both accumulators
+            const int twin_upto = DIAG ? sh.misc[d.nwaves + 2] : -1;   // last layer with own clear-sky rows, -1: none
             auto layer = [&](Stream &t, FT tau, FT ssa, FT gg, int k, int voff, int aoff, FT &Rdir, FT &Tdir, FT &Rdif,
-                             FT &Tdif, bool recompute) {
+                             FT &Tdif, bool recompute, bool also_twin) {
                 t.tau_cum += tau;
                 const FT dir_k = dir_top * m_exp_neg(t.tau_cum * inv_mu0);  // shortwave_2stream.jl:318-327
                 if (recompute) sw_2stream_coeffs(tau, ssa, gg, mu0, inv_mu0, Rdir, Tdir, Rdif, Tdif);
@@ -204,11 +208,21 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 t.beta = beta_n;
 #ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 if (RR_ACC_ATOMIC && !BAND) {
-                    wave_add_to(&acc[k * NA + aoff + 2], dir_k * amask);
-                    wave_add_to(&acc[k * NA + aoff + 1], t.delta * amask);
+                    const FT rdir = row_sum(dir_k * amask), rdel = row_sum(t.delta * amask);
+                    if ((threadIdx.x & 15) == 15) {   // wave_add_to: the four rows' lanes add their row sums
+                        (void)__hip_atomic_fetch_add(&acc[k * NA + aoff + 2], rdir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_add(&acc[k * NA + aoff + 1], rdel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (DIAG && also_twin) {
+                            (void)__hip_atomic_fetch_add(&acc[k * NA + 5], rdir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            (void)__hip_atomic_fetch_add(&acc[k * NA + 4], rdel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
                 } else {
                     const FT sdir = seg_sum<BAND>(dir_k * amask), sdel = seg_sum<BAND>(t.delta * amask);
-                    if (writer) { acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel; }
+                    if (writer) {
+                        acc[k * NA + aoff + 2] = sdir; acc[k * NA + aoff + 1] = sdel;
+                        if (DIAG && also_twin) { acc[k * NA + 5] = sdir; acc[k * NA + 4] = sdel; }
+                    }
                 }
 #endif
                 t.dir_above = dir_k;
@@ -235,11 +249,15 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                         if (DIAG && cld_k) increment_2stream(tau_c, ssa_c, g_c, cr.x, cr.y, cr.z);
                     }
                     FT Rdir, Tdir, Rdif, Tdif;
-                    layer(S, tau, ssa, gg, k, 0, 0, Rdir, Tdir, Rdif, Tdif, true);
+                    const bool twin_same = DIAG && k > twin_upto;
+                    layer(S, tau, ssa, gg, k, 0, 0, Rdir, Tdir, Rdif, Tdif, true, twin_same);
                     if (DIAG) {
-                        // without a cloud in this lane's sample the clear layer IS the all-sky layer: reuse its coefficients
-                        if (!cld_k) { tau_c = tau; ssa_c = ssa; g_c = gg; }
-                        layer(C, tau_c, ssa_c, g_c, k, 3, 3, Rdir, Tdir, Rdif, Tdif, cld_k);
+                        if (twin_same) C = S;
+                        else {
+                            // without a cloud in this lane's sample the clear layer IS the all-sky layer: reuse its coefficients
+                            if (!cld_k) { tau_c = tau; ssa_c = ssa; g_c = gg; }
+                            layer(C, tau_c, ssa_c, g_c, k, 3, 3, Rdir, Tdir, Rdif, Tdif, cld_k, false);
+                        }
                     }
                 }
             }
@@ -258,19 +276,26 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             }
             // ---- sweep 2, bottom-up: fluxes ----
             constexpr int DBT = DIAG ? DB / 2 : DB;
-            for (int kl = 0; kl < nlay; kl += DBT) {
+            // DIAG: layers [0, twin_upto] carry their own clear-sky rows, the layers above them share the all-sky rows
+            for (int phase = 0; phase < (DIAG ? 2 : 1); phase++) {
+            const int k_lo = DIAG && phase == 1 ? twin_upto + 1 : 0, k_end = DIAG && phase == 0 ? twin_upto + 1 : nlay;
+            const bool own = phase == 0;
+            for (int kl = k_lo; kl < k_end; kl += DBT) {
                 FT A[DBT], B[DBT], BE[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], BEc[DIAG ? DBT : 1];
 #pragma unroll
                 for (int j = 0; j < DBT; j++) {
-                    const int k = kl + j < nlay ? kl + j : nlay - 1;
+                    const int k = kl + j < k_end ? kl + j : k_end - 1;
                     sw.get3(k, 0, A[j], B[j], BE[j]);
-                    if (DIAG) sw.get3(k, 3, Ac[j], Bc[j], BEc[j]);
+                    if (DIAG) {
+                        if (own) sw.get3(k, 3, Ac[j], Bc[j], BEc[j]);
+                        else { Ac[j] = A[j]; Bc[j] = B[j]; BEc[j] = BE[j]; }
+                    }
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        const bool in = kl + j < nlay;
+                        const bool in = kl + j < k_end;
                         if (in) U = A[j] * U + B[j];
                         pu[j] = in ? U * amask : FT(0);
                         pb[j] = in ? BE[j] * U * amask : FT(0);
@@ -282,7 +307,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const int j = i + 4 * (lane >> 4), lev = kl + j + 1;
-                            if (kl + j < nlay) {
+                            if (kl + j < k_end) {
                                 acc[lev * NA] = wu[i];
                                 acc[lev * NA + 1] = (acc[lev * NA + 1] + wb[i]) + acc[lev * NA + 2];
                             }
@@ -292,7 +317,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                     FT pa[16], pc[16];  // two streams x (U, beta U) x 8 levels: one 16-value reduction per stream
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const bool in = kl + j < nlay;
+                        const bool in = kl + j < k_end;
                         if (in) { U = A[j] * U + B[j]; Uc = Ac[j] * Uc + Bc[j]; }
                         pa[j] = in ? U * amask : FT(0);
                         pa[j + 8] = in ? BE[j] * U * amask : FT(0);
@@ -307,7 +332,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
                             const int j = i + 4 * (r & 1), lev = kl + j + 1;
-                            if (kl + j < nlay) {
+                            if (kl + j < k_end) {
                                 if (r < 2) { acc[lev * NA] = wa[i]; acc[lev * NA + 3] = wc[i]; }
                                 else {
                                     acc[lev * NA + 1] = (acc[lev * NA + 1] + wa[i]) + acc[lev * NA + 2];
@@ -319,7 +344,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 } else {
 #pragma unroll
                     for (int j = 0; j < DBT; j++) {
-                        if (kl + j < nlay) {
+                        if (kl + j < k_end) {
                             const int lev = kl + j + 1;
                             U = A[j] * U + B[j];
                             const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
@@ -332,6 +357,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                         }
                     }
                 }
+            }
             }
         } else if (want_aod) {
             // night column: the reference still runs the optics, so the AOD diagnostic is defined
