@@ -74,8 +74,25 @@ __device__ __forceinline__ double m_cos(double x) { return cos(x); }
 // Division and reciprocal of well-scaled Float32 quantities in the per-g-point loops (optical
 // depths, albedos, two-stream denominators: never denormal or near overflow): v_rcp_f32 (1 ulp)
 // times the numerator.  Float64, and -DRR_PRECISE_F32, use the IEEE division.
+// Float64: v_rcp_f64 refined by two Newton steps (5 instructions), and for a quotient one residual correction on top
+// (8 instructions; the compiler's IEEE expansion with its scaling and fix-up steps is 13): at most 1 ulp for the well-scaled
+// operands of the g-point loops, far inside the Float64 parity budget (1e-11 relative).  A zero divisor gives NaN / inf
+// exactly where `1.0 / x` gives inf, and every such call site selects its result away (tau <= 0).
+#ifdef RR_PRECISE_F32
 __device__ __forceinline__ double m_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ double m_div(double a, double b) { return a / b; }
+#else
+__device__ __forceinline__ double m_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double m_div(double a, double b) {
+    const double r = m_rcp(b), q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+#endif
 #ifdef RR_PRECISE_F32
 __device__ __forceinline__ float m_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float m_div(float a, float b) { return a / b; }
@@ -97,7 +114,7 @@ __device__ __forceinline__ float ieee_div(float a, float b) {
     return fmaf(fmaf(-b, q, a), rc, q);
 #endif
 }
-__device__ __forceinline__ double ieee_div(double a, double b) { return a / b; }
+__device__ __forceinline__ double ieee_div(double a, double b) { return m_div(a, b); }   // (Newton + residual correction: <= 1 ulp)
 template <typename FT> __device__ __forceinline__ FT m_max(FT a, FT b) { return a > b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_min(FT a, FT b) { return a < b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT(0) ? -a : a; }
