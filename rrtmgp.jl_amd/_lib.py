@@ -107,10 +107,13 @@ def lib():
             # When PyTorch is present it must be imported first: its wheel bundles a HIP runtime
             # with the same SONAME (libamdhip64.so.7), and the library has to share that one
             # runtime instance to use torch's streams and device tensors in place.
-            try:
-                import torch  # noqa: F401
-            except ImportError:
-                pass
+            # RRTMGP_HIP_NO_TORCH=1: a host-array caller that does not use torch tensors (what a Julia host is) runs on the
+            # system's HIP runtime instead of the one bundled with the PyTorch wheel
+            if not os.environ.get("RRTMGP_HIP_NO_TORCH"):
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             L = C.CDLL(SO_PATH)
         except OSError as e:
             raise RRTMGPHipError(f"cannot load {SO_PATH}: {e}") from e

@@ -1014,23 +1014,47 @@ static int pipeline_resources(rrtmgp_workspace *ws) {
 template <typename F>
 static int run_column_pipeline(rrtmgp_workspace *ws, size_t ncol, size_t E, bool vmr_gm, F &&chunk) {
     TRY(pipeline_resources(ws));
-    // chunk size: small enough that the first upload and the last download (the only copies nothing overlaps) are a
-    // small share, large enough that every chunk still fills the persistent grid several times over
-    static const size_t per_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 8192;
-    const int nchunk = (int)std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
-    // (equal chunks.  A ramped pipeline — first and last chunk cut into quarters so that the only copies nothing overlaps
-    // shrink — was measured on the Layer-2 step and is slower, 38.6 vs 38.3 ms: what a chunked step loses against two big
-    // launches is the tail of the persistent grid at the end of every launch, not the exposed copies; tools/experiments/README.md)
+    // Chunk sizes.  Two costs pull in opposite directions: nothing overlaps the first chunk's upload and the last chunk's
+    // download (small chunks at both ends), and every launch ends with the tail of its persistent grid — the last column of
+    // each workgroup finishes alone — which a step cut into 16 equal chunks pays 16 times per kernel (4.4 ms of a 38 ms
+    // Layer-2 step, tools/experiments/README.md).  So the chunks ramp: 4 096 columns first, doubling up to `ramp_max`, the
+    // same downwards at the end, the middle in equal pieces no larger than `ramp_max`.  RRTMGP_HIP_HOST_CHUNK_COLUMNS = n:
+    // equal chunks of about n columns instead (the pipeline of rounds 2-3 with n = 8192).
+    static const size_t fixed_chunk = getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_CHUNK_COLUMNS")) : 0;
+    static const size_t ramp_max = getenv("RRTMGP_HIP_HOST_RAMP_MAX") ? (size_t)atol(getenv("RRTMGP_HIP_HOST_RAMP_MAX")) : 32768;
+    std::vector<size_t> edge{0};
+    {
+        std::vector<size_t> up;
+        size_t ramp = 0;
+        for (size_t n = 4096; n < ramp_max; n *= 2) { up.push_back(n); ramp += n; }
+        if (fixed_chunk || ncol < 2 * ramp + ramp_max / 2 || up.empty()) {
+            const size_t per_chunk = fixed_chunk ? fixed_chunk : 8192;
+            const size_t nc = std::min<size_t>(32, std::max<size_t>(2, ncol / std::max<size_t>(per_chunk, 1024)));
+            const size_t per = (ncol + nc - 1) / nc;
+            for (size_t c = 1; c <= nc && edge.back() < ncol; c++) edge.push_back(std::min(ncol, per * c));
+        } else {
+            for (size_t n : up) edge.push_back(edge.back() + n);
+            const size_t mid = ncol - 2 * ramp, nmid = (mid + ramp_max - 1) / ramp_max;
+            for (size_t c = 1; c <= nmid; c++) edge.push_back(ramp + mid * c / nmid);
+            for (size_t i = up.size(); i-- > 0;) edge.push_back(edge.back() + up[i]);
+        }
+    }
+    const int nchunk = (int)edge.size() - 1;
     RR_HIP(hipStreamSynchronize(ws->stream));  // earlier work of the caller on this workspace
+    // One copy stream, two staging sets: chunk c + 1 is uploaded while chunk c is solved, and chunk c - 1 comes home behind
+    // that upload.  (Downloads on a second stream over three staging sets — PCIe is full duplex — measured slower: 38.3 vs
+    // 37.4-37.8 ms for the Layer-2 step, 39.7 vs 38.0 ms for two separate solves; every cross-stream event costs the copy
+    // queue more than the overlap returns, and an event recorded between the copies of one stream makes the runtime fall
+    // back to shader copies that queue behind the persistent solve grid.  tools/experiments/README.md, round 4.)
     Stager prev{ws, {}};
     prev.cs = ws->copy_stream;
     int rc = RRTMGP_OK;
+    // (the staging buffers grow to the largest chunk's size during the first call only — hipFree waits for the device, so a
+    // buffer is never released under a copy in flight — and stay there: warm calls allocate nothing)
     for (int c = 0; c < nchunk && rc == RRTMGP_OK; c++) {
-        const size_t per = (ncol + nchunk - 1) / nchunk;  // equal chunks, the last one shorter: staging buffers never grow mid-way
-        const size_t c0 = std::min(ncol, per * c), c1 = std::min(ncol, per * (c + 1));
-        if (c1 == c0) break;
+        const size_t c0 = edge[c], c1 = edge[c + 1];
         ColumnSlice sl{E, c0};
-        std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads have completed
+        std::swap(ws->stage, ws->stage_alt);  // the set chunk c - 2 used; its downloads are ahead of these uploads in the copy stream
         Stager st{ws, {}};
         st.cs = ws->copy_stream;
         // the well-mixed vmr vector (VmrGM) does not depend on the column range: chunks 0 and 1 put it into the two
@@ -1744,6 +1768,7 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
     }
     for (auto &b : ws->stage) if (b.ptr) (void)rr_free(b.ptr);
     for (auto &b : ws->stage_alt) if (b.ptr) (void)rr_free(b.ptr);
+
     for (int i = 0; i < 2; i++) {
         if (ws->ev_in[i]) (void)hipEventDestroy(ws->ev_in[i]);
         if (ws->ev_k[i]) (void)hipEventDestroy(ws->ev_k[i]);

@@ -1,10 +1,16 @@
-python -m pytest tests/test_strided_views.py tests/test_update_fluxes.py tests/test_gpu_parity.py -m gpu -q 2>&1 | tail -12
+#!/bin/bash
+# Runs on the GPU box: the host-array Layer-2 step (bench.py --l2 fused) and the two-solve host leg under different chunk
+# schedules of the column pipeline, same session.  Output: gpurun_out/l2_host_ab.txt
+OUT=gpurun_out/l2_host_ab.txt; mkdir -p gpurun_out; : > $OUT
+python -m pytest tests/test_update_fluxes.py tests/test_gpu_parity.py tests/test_abi_contracts.py -m gpu -q -k "pipeline or host or alloc or thread" 2>&1 | tail -3 >> $OUT
+run() {  # label, env assignments
+  for mode in "--l2 fused" "--host"; do
+    env $2 python bench.py $mode --leg x --steps 10 --warmup 3 | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-36s %-12s %.3f M  %.2f ms' % ('$1', '$mode', j['value']/1e6, j['ms_per_step']))" >> $OUT
+  done
+}
 for r in 1 2; do
-for v in ramp noramp; do
-  if [ $v = noramp ]; then export RRTMGP_HIP_HOST_NO_RAMP=1; else unset RRTMGP_HIP_HOST_NO_RAMP; fi
-  python bench.py --l2 fused --leg x --steps 10 --warmup 3 | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v fused %.3f M  %.2f ms min %.2f' % (j['value']/1e6, j['ms_per_step'], j['min_ms']))"
-  python bench.py --host --leg x --steps 10 --warmup 3 | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v host  %.3f M  %.2f ms' % (j['value']/1e6, j['ms_per_step']))"
-done; done
-for c in 4096 6144 12288 16384; do
-  RRTMGP_HIP_HOST_CHUNK_COLUMNS=$c python bench.py --l2 fused --leg x --steps 10 --warmup 3 | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('chunk $c fused %.3f M  %.2f ms' % (j['value']/1e6, j['ms_per_step']))"
+  run "ramp 4k..32k (default)" "X=1"
+  run "equal 8192 (round 3)" "RRTMGP_HIP_HOST_CHUNK_COLUMNS=8192"
+  run "ramp, system HIP runtime (no torch)" "RRTMGP_HIP_NO_TORCH=1"
 done
+cat $OUT
