@@ -527,12 +527,8 @@ __device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDim
                                       const DevCld<FT> *cld, const DevAero<FT> *aero, const DevState<FT> &as, int col) {
     const int nlay = d.nlay, nlev = d.nlev, tid = threadIdx.x, nt = blockDim.x;
     const FT *ld = as.layerdata + (size_t)4 * nlay * col;
-#ifdef RR_EXP_PREP_SAME_LANES
-    const int tid2 = tid;
-#else
     // thread index rotated by one wavefront: the loops after the layer records start on the wavefronts that have none
     const int tid2 = nt > 64 ? (tid >= 64 ? tid - 64 : tid + nt - 64) : tid;
-#endif
     for (int k = tid; k < nlay; k += nt) {
         const FT col_dry = ld[4 * k + 0], p = ld[4 * k + 1], t = ld[4 * k + 2];
         LayerRec<FT> rec;
@@ -762,13 +758,9 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
     const int nlay = d.nlay, nb = d.nbnd, tid = threadIdx.x, nt = blockDim.x;
     const int NE = lk.n_eta;
     for (int u = tid; u < CHK * nb; u += nt) {
-#ifdef RR_PREP_KK_MINOR
-        const int b = u / CHK, kk = u % CHK, k = k0 + kk;  // CHK is a power of two
-#else
         // consecutive lanes take consecutive bands of one layer: the record stores below are contiguous in LDS
         // (16-byte stride between lanes instead of 256) and the sh.lay[k] / sh.lev[k] reads are broadcasts
         const int kk = u / nb, b = u - kk * nb, k = k0 + kk;
-#endif
         if (kk >= kn) continue;
         const int t = kk * NBMAX + b;
         // Planck band sources at levels k0 .. k0 + kn (interp1d_equispaced, compute_optical_props.jl:180-186): the
@@ -844,11 +836,7 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
             if (sh.lay[k].aero_mask) {
                 const size_t o = (size_t)RRTMGP_N_AEROSOLS * ((size_t)nlay * col + k);
                 FT ta, tsa, tsga;
-#ifdef RR_EXP_AERO_CONST  // timing-only: no species loop / table lookups (bounds what hoisting them out of the band tasks could save)
-                ta = as.aero_mass[o] + FT(1e-3); tsa = FT(0.5) * ta; tsga = FT(0.25) * ta;
-#else
                 lookup_aerosol(*aero, sh, as.aero_mass + o, as.aero_size + o, b, k, ta, tsa, tsga);
-#endif
                 if (!d.lw && b == aero->iband_550nm - 1) { sh.lay[k].aod_t = ta; sh.lay[k].aod_ts = tsa; }
                 if (d.twostream) {  // aerosol_optics.jl:113-122
                     FT g_aero = tsga / m_max(Num<FT>::eps(), tsa);
@@ -962,11 +950,7 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     GasLoads<FT, SW> G;
     const LayerRec<FT> &L = sh.lay[k];
     const int li = L.idx;
-#ifdef RR_EXP_FAKE_ROWS  // timing-only: the (T, p) row part of every gather address is dropped (bounds what precomputed offsets could save)
-    const unsigned jT = 0, jP = 0, tropo = li >> 16;
-#else
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
-#endif
     G.fP = L.fP;
     G.ray_fac = SW ? L.ray_fac : FT(0);
     const int r = kk * NBMAX + lb.ibnd;
@@ -994,16 +978,10 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
         G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
     } else {
-#ifdef RR_EXP_LW_K_ONLY  // timing-only: 4-byte gathers of k alone at the pairs' addresses (the Planck fraction copies k)
-        auto one = [](const char *bb, unsigned o) { const FT v = ldg<FT>(bb, o); return V2<FT>{v, v}; };
-        const V2<FT> a = one(b0, o1), b = one(b1, o1), c = one(b2, o1), d = one(b3, o1);
-        const V2<FT> e = one(b0, o2), f = one(b1, o2), g = one(b2, o2), h = one(b3, o2);
-#else
         const V2<FT> a = ldg<V2<FT>>(b0, o1), b = ldg<V2<FT>>(b1, o1);
         const V2<FT> c = ldg<V2<FT>>(b2, o1), d = ldg<V2<FT>>(b3, o1);
         const V2<FT> e = ldg<V2<FT>>(b0, o2), f = ldg<V2<FT>>(b1, o2);
         const V2<FT> g = ldg<V2<FT>>(b2, o2), h = ldg<V2<FT>>(b3, o2);
-#endif
         G.k000 = a.x; G.k100 = b.x; G.k010 = c.x; G.k110 = d.x; G.q000 = e.x; G.q100 = f.x; G.q010 = g.x; G.q110 = h.x;
         G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
         G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
@@ -1015,11 +993,7 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     // gases owns one all-padding group) are 0 in the table and carry a zero scaling, which leaves the in-order sum
     // unchanged.  When some band of this wavefront has a second group (5-8 contributors) in this region, its loads
     // are issued too; lanes of the other bands re-read their first group with zero scalings.
-#ifdef RR_EXP_NO_MINOR  // timing-only experiment: no minor-gas gathers
-    G.n = 0;
-#else
     G.n = lb.m_n(tropo);
-#endif
     const char *kmn = lk.arena;
     const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
     G.a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
@@ -1034,14 +1008,8 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     // g1 / s1 stay unset unless the second group is loaded (gas_finish reads them under the same wave-uniform flag):
     // zero-filling them costs 20 v_mov per layer, and invites the compiler to run the second group's 20 FMAs always
     G.two = false;
-#if defined(RR_EXP_NO_MINOR) || defined(RR_EXP_ZERO_G1)
-    G.g0 = G.g1 = Corners<FT>{z4, z4, z4, z4};
-    G.s0 = G.s1 = z4;
-#endif
-#ifndef RR_EXP_NO_MINOR
     G.g0 = corners(G.a1, G.a2);
     G.s0 = *reinterpret_cast<const V4<FT> *>(G.ms);
-#ifndef RR_EXP_MINOR_ONE_GROUP
     G.two = __any(G.n > MINOR_GROUP);
     if (G.two) {
         const bool mine = G.n > MINOR_GROUP;
@@ -1050,8 +1018,6 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         G.s1 = *reinterpret_cast<const V4<FT> *>(G.ms + (mine ? MINOR_GROUP : 0));
         if (!mine) G.s1 = z4;
     }
-#endif
-#endif
     return G;
 }
 
@@ -1078,13 +1044,11 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
     if (G.two) {
         consume(G.g1, G.s1);
         const char *kmn = lk.arena;
-#ifndef RR_EXP_NO_MINOR_TAIL  // timing-only: no third-and-later groups (wrong for bands with more than 8 minor gases)
         for (int i0 = 2 * MINOR_GROUP; i0 < G.n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases (rare; exposed)
             const unsigned x1 = G.a1 + __umul24((unsigned)(i0 / MINOR_GROUP), G.gstep), x2 = x1 - G.a1 + G.a2;
             const Corners<FT> c{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + G.ncb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + G.ncb, x2)};
             consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0));
         }
-#endif
     }
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
     // cm (1-fP) (1-fT) ((1-fe) k000 + fe k100) + ... regrouped as amp * (w11 k000 + w21 k100) + ...
@@ -1180,22 +1144,14 @@ __device__ __forceinline__ bool mask_bit(uint64_t m0, uint64_t m1, int k) {
 // is the current layer, shift right); otherwise nlay-1, nlay-2, ... (bit 63 is the current layer, shift left).
 // The word switch happens once per 64 layers: as a real (wave-uniform) branch it costs the scalar compare that is there
 // anyway; if-converted it is two v_cndmask_b32 in every layer.  The empty asm keeps the compiler from if-converting.
-#ifndef RR_EXP_REFILL_SELECT
 #define RR_REFILL_BRANCH() asm volatile("" ::: "memory")
-#else
-#define RR_REFILL_BRANCH() (void)0
-#endif
 template <bool UP>
 struct MaskWalk {
     uint64_t cur, other;
     const uint64_t *base;  // wave-uniform; != nullptr: more than 128 layers, lane t's word w is base[w * 256 + t] (LDS)
     __device__ __forceinline__ const uint64_t *word(int w) const { return base + w * 256 + threadIdx.x; }
     __device__ __forceinline__ MaskWalk(uint64_t m0, uint64_t m1, int nlay, const uint64_t *lds_words = nullptr) {
-#ifdef RR_EXP_MASK_128_ONLY  // A/B: the register-only walker of columns up to 128 layers
-        base = nullptr;
-#else
         base = nlay > 128 ? lds_words : nullptr;
-#endif
         if (base) {
             const int top = (nlay - 1) >> 6;
             cur = UP ? *word(0) : *word(top) << (63 - ((nlay - 1) & 63));
@@ -1252,52 +1208,18 @@ struct Sweep {
     unsigned lane;  // threadIdx.x * sizeof(FT)
     static constexpr unsigned row = SWEEP_LANES * sizeof(FT);  // a compile-time stride: neighbouring rows are immediate offsets
     __device__ __forceinline__ FT *ptr(int lev, int a) const {
-#ifdef RR_EXP_SCRATCH_ROW0  // timing-only experiment: every access hits level 0's rows (same instructions, 1/nlev of the footprint)
-        lev = 0;
-#endif
         return reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
     }
-    __device__ __forceinline__ void put(int lev, int a, FT v) const {
-#ifdef RR_EXP_SCRATCH_ROW0_STORES  // timing-only: the stores alone lose their footprint
-        lev = 0;
-#endif
-#ifdef RR_SCRATCH_NT_STORE
-        __builtin_nontemporal_store(v, ptr(lev, a));
-#else
-        *ptr(lev, a) = v;
-#endif
-    }
-    __device__ __forceinline__ FT get(int lev, int a) const {
-#ifdef RR_EXP_SCRATCH_ROW0_LOADS  // timing-only: the loads alone lose their footprint
-        lev = 0;
-#endif
-#ifdef RR_SCRATCH_NT_LOAD
-        return __builtin_nontemporal_load(ptr(lev, a));
-#else
-        return *ptr(lev, a);
-#endif
-    }
-    // Three values of one level at once (a = 0, or 3 for the clear-sky twin).  Default: three rows, three 4-byte accesses
-    // per lane.  RR_EXP_SCRATCH_X3 (A/B): the three values of a lane sit next to each other ([level][lane][3] records:
-    // the same bytes and cache lines per wavefront, one 12-byte access per lane instead of three).
-    struct V3 { FT x, y, z; };
-    __device__ __forceinline__ V3 *rec(int lev, int a) const {
-        return reinterpret_cast<V3 *>(base + ((unsigned)(lev * NV + a) * row + 3 * lane));
-    }
+    __device__ __forceinline__ void put(int lev, int a, FT v) const { *ptr(lev, a) = v; }
+    __device__ __forceinline__ FT get(int lev, int a) const { return *ptr(lev, a); }
+    // Three values of one level at once (a = 0, or 3 for the clear-sky twin): three rows, three 4-byte accesses per lane.
+    // ([level][lane][3] records, one 12-byte access per lane, were measured in round 3: fewer memory instructions, more
+    // VALU, slower — tools/experiments/README.md.)
     __device__ __forceinline__ void put3(int lev, int a, FT x, FT y, FT z) const {
-#ifdef RR_EXP_SCRATCH_X3
-        *rec(lev, a) = V3{x, y, z};
-#else
         put(lev, a, x); put(lev, a + 1, y); put(lev, a + 2, z);
-#endif
     }
     __device__ __forceinline__ void get3(int lev, int a, FT &x, FT &y, FT &z) const {
-#ifdef RR_EXP_SCRATCH_X3
-        const V3 v = *rec(lev, a);
-        x = v.x; y = v.y; z = v.z;
-#else
         x = get(lev, a); y = get(lev, a + 1); z = get(lev, a + 2);
-#endif
     }
 };
 

@@ -14,11 +14,6 @@
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
 #include "device.h"
 
-#ifdef RR_EXP_NO_CHUNK_BARRIER  // timing-only experiment: the chunk loop's barriers removed (races: results are wrong)
-#define RR_CHUNK_SYNC() ((void)0)
-#else
-#define RR_CHUNK_SYNC() __syncthreads()
-#endif
 
 namespace rrtmgp {
 
@@ -181,10 +176,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             auto adding = [&](FT &alb, FT &sr, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff) {
                 const FT denom = m_rcp(FT(1) - Rdif * alb);  // Eq 10
                 sw.put3(kl, voff, Tdif * denom /* A */, (Rdif * sr + src_dn) * denom /* B */, alb);
-#ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 const FT ss = seg_sum<BAND>(sr * amask);
                 if (writer) acc[kl * NA + aoff] = ss;
-#endif
                 const FT alb_n = Rdif + Tdif * Tdif * alb * denom;  // Eq 9
                 sr = src_up + Tdif * denom * (sr + alb * src_dn);   // Eq 11
                 alb = alb_n;
@@ -202,12 +195,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 mw.refill(k0);
-                RR_CHUNK_SYNC();
-#ifdef RR_EXP_PREP_ONCE  // timing-only experiment: chunk records prepared for the first chunk only (barriers kept)
-                if (c == 0)
-#endif
+                __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                RR_CHUNK_SYNC();
+                __syncthreads();
                 for (int kk = 0; kk < kn; kk++) {
                     const int k = k0 + kk;
                     FT tau, ssa, gg, pfrac;
@@ -433,9 +423,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
         for (int c = nchunk - 1; c >= 0; c--) {
             const int k0 = c * CHK, kn = min(CHK, nlay - k0);
             mw.refill(k0 + kn - 1);
-            RR_CHUNK_SYNC();
+            __syncthreads();
             prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-            RR_CHUNK_SYNC();
+            __syncthreads();
             for (int kk = kn - 1; kk >= 0; kk--) {
                 const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
                 FT tau, ssa, pfrac;

@@ -13,11 +13,6 @@
 // cloud-cover and 550 nm AOD diagnostics as the reference does.
 #include "device.h"
 
-#ifdef RR_EXP_NO_CHUNK_BARRIER  // timing-only experiment: the chunk loop's barriers removed (races: results are wrong)
-#define RR_CHUNK_SYNC() ((void)0)
-#else
-#define RR_CHUNK_SYNC() __syncthreads()
-#endif
 
 namespace rrtmgp {
 
@@ -139,7 +134,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
-                RR_CHUNK_SYNC();
+                __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk;
                     FT tau, ssa, pf;
@@ -206,7 +201,6 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
                 t.delta = s_dn + Tdif * den * (t.delta + t.beta * s_up);
                 t.beta = beta_n;
-#ifndef RR_EXP_NO_LAYER_SUMS  // timing-only experiment: no g-point sums inside the layer loop
                 if (RR_ACC_ATOMIC && !BAND) {
                     const FT rdir = row_sum(dir_k * amask), rdel = row_sum(t.delta * amask);
                     if ((threadIdx.x & 15) == 15) {   // wave_add_to: the four rows' lanes add their row sums
@@ -224,18 +218,14 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                         if (DIAG && also_twin) { acc[k * NA + 5] = sdir; acc[k * NA + 4] = sdel; }
                     }
                 }
-#endif
                 t.dir_above = dir_k;
             };
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 mw.refill(k0 + kn - 1);
-                RR_CHUNK_SYNC();
-#ifdef RR_EXP_PREP_ONCE
-                if (c == nchunk - 1)
-#endif
+                __syncthreads();
                 prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
-                RR_CHUNK_SYNC();
+                __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
                     FT tau, ssa, pf, gg = FT(0);
