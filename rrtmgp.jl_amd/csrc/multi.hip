@@ -30,8 +30,8 @@ const rrtmgp_lookup *lookup_on(const rrtmgp_lookup *lk, int device) {
 }
 
 // ---- shard workers ---------------------------------------------------------------------------------------------------
-// One persistent host thread per shard beyond the first (shard 0 runs on the calling thread), parked on a condition
-// variable between calls: a call costs two notifications per shard instead of a thread spawn + join (multi_run used to
+// One persistent host thread per shard (round 4: shard 0 too — on the calling thread it ran unbound, wherever the host
+// model's thread happened to be), parked on a condition variable between calls: a call costs two notifications per shard instead of a thread spawn + join (multi_run used to
 // create and join std::threads on every entry).  A worker is bound to the CPUs that are local to its GPU's PCIe root
 // (/sys/bus/pci/devices/<bus id>/local_cpulist): at 8 GPUs the staging copies of one process move > 100 GB/s, which only
 // works from the memory controllers next to each GPU.  RRTMGP_HIP_NO_NUMA_BIND=1 leaves the threads unbound.
@@ -71,7 +71,7 @@ struct ShardWorkers {
         if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);  // failure (cgroup limits) is harmless
     }
     explicit ShardWorkers(const std::vector<rrtmgp_workspace *> &shards) {
-        for (size_t s = 1; s < shards.size(); s++) {
+        for (size_t s = 0; s < shards.size(); s++) {
             w.emplace_back(new Worker());
             Worker *me = w.back().get();
             const int device = shards[s]->device;
@@ -136,12 +136,11 @@ int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, 
     } else {
         if (!ws->workers && n > 1) ws->workers = new ShardWorkers(ws->shards);
         std::vector<std::function<void()>> jobs(n);
-        for (size_t s = 1; s < n; s++) {
+        for (size_t s = 0; s < n; s++) {
             jobs[s] = [&run, s] { run(s); };
-            ws->workers->start(s - 1, &jobs[s]);
+            ws->workers->start(s, &jobs[s]);
         }
-        run(0);
-        for (size_t s = 1; s < n; s++) ws->workers->wait(s - 1);
+        for (size_t s = 0; s < n; s++) ws->workers->wait(s);
     }
     for (size_t s = 0; s < n; s++)
         if (rc[s] != RRTMGP_OK) return set_error(rc[s], "shard " + std::to_string(s) + ": " + msg[s]);

@@ -202,3 +202,26 @@ def test_bench_strong_scaling_mode_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "4097 columns split over 2 GPU(s)" in d["config"]["workload"]
     assert abs(d["value"] - 4097 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_layer2_host_leg():
+    """`bench.py --l2 fused|split`: the Layer-2 step of a host model on host arrays through the Python mirror; the record
+    carries the bytes that crossed PCIe per column, and the fused step uploads the state once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = {}
+    for mode in ("fused", "split"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--l2", mode, "--leg", "x", "--ncol", "20480", "--nlay", "32",
+                            "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        rec[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert rec[mode]["unit"] == "columns/s" and rec[mode]["value"] > 0 and rec[mode]["ncol"] == 20480
+    assert rec["fused"]["calls_per_step"] == 1 and rec["split"]["calls_per_step"] == 3
+    assert rec["fused"]["h2d_bytes_per_column"] < 0.55 * rec["split"]["h2d_bytes_per_column"]
+    # state (4 + 2 + 5 layer arrays, 2 level arrays, t_sfc, lat) + boundary conditions, Float32, 32 layers, 16 / 14 bands
+    want = 4 * ((4 + 2 + 5) * 32 + 2 * 33 + 2 + 16 + 2 + 2 * 14)
+    assert want <= rec["fused"]["h2d_bytes_per_column"] <= want + 8
