@@ -103,6 +103,9 @@ def parse_args(argv=None):
                     help="time the Layer-2 step of a host model (update_fluxes! on HOST arrays: prepare_atmosphere! + LW + SW + net, "
                          "AllSkyRadiation): `fused` = ONE call of rrtmgp_hip_update_fluxes (state staged once), `split` = the "
                          "reference's four steps as separate calls (prepare, LW, SW staged separately; net sum on the host)")
+    ap.add_argument("--fused-step", action="store_true",
+                    help="a step is ONE rrtmgp_hip_update_fluxes call (LW + SW + net sum on one workspace; short steps "
+                         "overlap the two solvers) instead of two solve calls")
     ap.add_argument("--no-legs", action="store_true", help="only the headline measurement (no variant / host / CPU legs)")
     ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)   # child-process mode: compact JSON, no legs
     return ap.parse_args(argv)
@@ -250,7 +253,7 @@ def main():
             as_d, lb_d, sb_d = as_d._map(rep), lb_d._map(rep), sb_d._map(rep)
     wdev = shards if shards else local_rank
     ws_lw = rte.Workspace(ncol, nlay, ft, wdev)
-    ws_sw = rte.Workspace(ncol, nlay, ft, wdev)
+    ws_sw = ws_lw if args.fused_step else rte.Workspace(ncol, nlay, ft, wdev)
     noscat = args.lw_solver == "noscat"
     slv_lw = (rte.NoScatLWRTE(ncol, nlay, ft, lb_d, device=local_rank, flux_device=None if args.host else dev, workspace=ws_lw,
                               n_gauss_angles=args.angles) if noscat else
@@ -273,7 +276,19 @@ def main():
             slv_sw_c = rte.TwoStreamSWRTE(ncol, nlay, ft, sb_d, device=local_rank, flux_device=fdev, workspace=slv_sw.ws)
             slv_lw_c.flux, slv_sw_c.flux = clr_lw, clr_sw
 
+    net_d = None
+    if args.fused_step:
+        if args.clear_sky_diag == "two-solves" or args.lw_only or noscat:
+            raise SystemExit("--fused-step is the two-stream LW + SW step (optionally with --clear-sky-diag one-pass)")
+        net_d = np.empty((nlay + 1, ncol), ft, order="F") if args.host else torch.empty((ncol, nlay + 1), dtype=lb_d.sfc_emis.dtype, device=dev)
+
     def step():
+        if args.fused_step:
+            one = args.clear_sky_diag == "one-pass"
+            rte.update_fluxes(slv_lw, slv_sw, as_d, d_lw, d_sw, d_lw_cld, d_sw_cld, d_lw_aero, d_sw_aero, seed=2026,
+                              col_offset=col_offset, net_flux=net_d, clear_flux_lw=clr_lw if one else None,
+                              clear_flux_sw=clr_sw if one else None)
+            return
         if args.clear_sky_diag == "two-solves":
             rte.solve_lw(slv_lw_c, as_d, d_lw, None, d_lw_aero, seed=2026, col_offset=col_offset)
             rte.solve_sw(slv_sw_c, as_d, d_sw, None, d_sw_aero, seed=2026, col_offset=col_offset)
@@ -474,6 +489,10 @@ def main():
                 # 4096 columns = 4 per resident workgroup, so the launch is one round of the persistent grid + its tail
                 "config4_4096x72_aerosols": run_leg("config4_4096x72_aerosols", ["--ncol", "4096", "--nlay", "72", "--aerosols",
                                                                                  "--steps", "50", "--warmup", "5"]),
+                # the same batch as ONE rrtmgp_hip_update_fluxes call on device arrays (LW + SW + net sum; a short step runs the
+                # two solvers on the workspace's two lanes)
+                "config4_fused_step_device": run_leg("config4_fused_step_device", ["--ncol", "4096", "--nlay", "72", "--aerosols",
+                                                                                   "--fused-step", "--steps", "50", "--warmup", "5"]),
             }
         # CPU baseline: the plain-C oracle (a port, not the Julia reference) on a bounded sample of
         # the same workload, on this box's host cores.  Rank 0, N = 1 only.

@@ -1002,6 +1002,7 @@ static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, con
 static int pipeline_resources(rrtmgp_workspace *ws) {
     if (ws->copy_stream) return RRTMGP_OK;
     RR_HIP(hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking));
+    RR_HIP(hipStreamCreateWithFlags(&ws->alt_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) {
         RR_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
         RR_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
@@ -1579,7 +1580,17 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
     }
     TRY(st.flush());  // packed small step: the one upload
 
-    // ---- [prepare] -> LW -> SW -> net, all on the workspace stream
+    // ---- [prepare] -> LW -> SW -> net on the workspace stream.  Two kinds of SHORT step run their SW kernels on the
+    // workspace's second lane instead (own stream, own sweep scratch; forked after the preparation, joined before the net sums):
+    //  - up to 2 columns per CU: the two grids fit the chip side by side (256 x 72 with aerosols: 0.296 -> 0.211 ms);
+    //  - a few columns per resident workgroup (BASELINE config 4's 4 096 columns are 4 each): the SW workgroups start in the
+    //    slots the LW tail frees — the last column of each workgroup finishes alone — worth 1-2 % from 4 096 to 12 288 columns.
+    // Between the two (1 024-2 048 columns: 3 % slower) and from 16 384 columns on (nothing) the step stays on one lane.
+    // tools/experiments/README.md round 4, step_overlap_ab.sh.  RRTMGP_HIP_STEP_OVERLAP=0/1 forces it off / on.
+    static const int force_overlap = getenv("RRTMGP_HIP_STEP_OVERLAP") ? atoi(getenv("RRTMGP_HIP_STEP_OVERLAP")) : -1;
+    const bool short_step = ncol <= 2 * (size_t)ws->n_cu || (ncol >= 16 * (size_t)ws->n_cu && ncol <= 48 * (size_t)ws->n_cu);
+    const bool overlap = !(chunk && !st.packed) && (force_overlap >= 0 ? force_overlap != 0 : short_step);
+    if (overlap) TRY(pipeline_resources(ws));
     if (prep) TRY(launch_prepare<FT>(ws, pv, *a->params, *po, false));
     const uint64_t seed = opts ? opts->seed : 0;
     const int64_t coff = opts ? opts->col_offset : 0;
@@ -1594,18 +1605,33 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
         return c;
     };
     FT *lw_clear_net = fl_lw.clear_net, *sw_clear_net = fl_sw.clear_net;
+    if (overlap) RR_HIP(hipEventRecord(ws->ev_k[0], ws->stream));  // `fork_at`
     if (diag_lw && (!twostream_lw || band_lw)) {
         const DevFlux<FT> c = clear_first(fl_lw);
         TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, nullptr, L.lw_aero, ds, emis, inc, inc_ld, c, n_angles, seed, coff, L.lw_max_int));
     }
     TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, L.lw_cld, L.lw_aero, ds, emis, inc, inc_ld, fl_lw, n_angles, seed, coff, L.lw_max_int));
-    if (diag_sw && band_sw) {
-        const DevFlux<FT> c = clear_first(fl_sw);
-        DevState<FT> dc = ds_sw;
-        dc.aod_sw_ext = dc.aod_sw_sca = nullptr;   // the all-sky solve writes the same values
-        TRY(launch_sw<FT>(ws, 1, *L.sw, nullptr, L.sw_aero, dc, mu0, toa, adir, adif, c, seed, coff, L.sw_max_int));
+    auto sw_lane = [&]() -> int {
+        if (diag_sw && band_sw) {
+            const DevFlux<FT> c = clear_first(fl_sw);
+            DevState<FT> dc = ds_sw;
+            dc.aod_sw_ext = dc.aod_sw_sca = nullptr;   // the all-sky solve writes the same values
+            TRY(launch_sw<FT>(ws, 1, *L.sw, nullptr, L.sw_aero, dc, mu0, toa, adir, adif, c, seed, coff, L.sw_max_int));
+        }
+        return launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int);
+    };
+    if (overlap) {
+        // fork: the second lane starts behind everything queued so far (uploads, preparation), NOT behind the LW kernels
+        // that were queued after `fork_at`; join: the net sums and the downloads wait for it
+        std::swap(ws->stream, ws->alt_stream); std::swap(ws->scratch, ws->alt_scratch);
+        int rc = hipStreamWaitEvent(ws->stream, ws->ev_k[0], 0) == hipSuccess ? sw_lane() : set_error(RRTMGP_EHIP, "hipStreamWaitEvent");
+        if (rc == RRTMGP_OK && hipEventRecord(ws->ev_k[1], ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipEventRecord");
+        std::swap(ws->stream, ws->alt_stream); std::swap(ws->scratch, ws->alt_scratch);
+        TRY(rc);
+        RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_k[1], 0));
+    } else {
+        TRY(sw_lane());
     }
-    TRY(launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int));
     if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
     if (clear_net) TRY(launch_net_sum<FT>(ws, lw_clear_net, sw_clear_net, clear_net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
     return chunk && !st.packed ? RRTMGP_OK : st.finish();
@@ -1774,7 +1800,9 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
         if (ws->ev_k[i]) (void)hipEventDestroy(ws->ev_k[i]);
     }
     if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
+    if (ws->alt_stream) (void)hipStreamDestroy(ws->alt_stream);
     if (ws->scratch.ptr) (void)rr_free(ws->scratch.ptr);
+    if (ws->alt_scratch.ptr) (void)rr_free(ws->alt_scratch.ptr);
     if (ws->bounce_h) (void)hipHostFree(ws->bounce_h);
     if (ws->bounce_d) (void)rr_free(ws->bounce_d);
     if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);

@@ -147,6 +147,10 @@ struct rrtmgp_workspace {
     // pipelined host path (column chunks: chunk c+1 is uploaded while chunk c is being solved)
     std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
     hipStream_t copy_stream = nullptr;
+    // second compute lane of a SHORT Layer-2 step (api.hip step_t): the SW kernels run on this stream with this sweep
+    // scratch while the LW kernels run on `stream`, so that one solver's workgroups fill the slots the other's tail frees
+    hipStream_t alt_stream = nullptr;
+    rrtmgp::DeviceBuffer alt_scratch;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
     // small host-array solves: every array travels through ONE page-locked bounce buffer (a host memcpy per array, one
     // DMA each way) instead of one DMA per array (~15 us each, 17 arrays per solve)

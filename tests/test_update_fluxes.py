@@ -109,6 +109,20 @@ def test_fused_step_equals_the_four_calls(tables64, FT, method, aerosols):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ncol,method", [(4500, "allsky"), (4200, "diag"), (600, "diag")])
+def test_short_step_on_two_lanes_equals_the_four_calls(tables64, ncol, method):
+    """A step of a few columns per resident workgroup (4 096-12 288 on 256 CUs; so is every step of up to 512 columns, which
+    the other tests cover) runs its SW kernels on the workspace's second lane, forked after the staged uploads and joined
+    before the net sums: same bits as the four calls on one stream.  600 columns: the one-lane range in between."""
+    fused, split = _pair(tables64, np.float32, method, True, ncol=ncol, nlay=10)
+    for seed in (3, 4):   # the second call reuses both lanes' scratch
+        L2.update_fluxes(fused, seed)
+        L2.update_fluxes(split, seed)
+    _assert_same(fused, split, method)
+    np.testing.assert_array_equal(L2.net_flux(fused), L2.lw_flux_net(fused) + L2.sw_flux_net(fused))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("interpolation,bottom", [(GA.ArithmeticMean, GA.SameAsInterpolation), (GA.UniformZ, GA.UseSurfaceTempAtBottom),
                                                   (GA.BestFit, GA.HydrostaticBottom)])
 @pytest.mark.parametrize("iso", [False, True])
