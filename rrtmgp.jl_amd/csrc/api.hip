@@ -319,18 +319,6 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         arena.resize(at + n, FT(0));
         return at;
     };
-    // (n_eta, n_p, n_t, n_gpt) -> [t][p][eta][gpt]
-    auto relayout4 = [&](const void *src, unsigned *off) -> int {
-        const FT *s = (const FT *)src;
-        const size_t at = arena_piece((size_t)NE * NP * NT * NG);
-        for (int64_t gq = 0; gq < NG; gq++)
-            for (int64_t t = 0; t < NT; t++)
-                for (int64_t p = 0; p < NP; p++)
-                    for (int64_t e = 0; e < NE; e++)
-                        arena[at + ((t * NP + p) * NE + e) * NG + gq] = s[e + NE * (p + NP * (t + NT * gq))];
-        *off = (unsigned)(at * sizeof(FT));
-        return RRTMGP_OK;
-    };
     // (n_eta, n_t, n) -> [t][eta][row], element c of the source at position dst_of_src[c] < row (the rest stays 0)
     auto relayout3 = [&](const void *src, int64_t n, int64_t row, const std::vector<int64_t> &dst_of_src, unsigned *off) -> int {
         const FT *s = (const FT *)src;
@@ -342,22 +330,27 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         return RRTMGP_OK;
     };
     g.t_planck = nullptr; g.tot_planck = nullptr;
-    if (d->is_sw) {
-        TRY(relayout4(d->kmajor, &g.off_kmajor));
-    } else {
-        RR_CHECK(d->planck_fraction && d->t_planck && d->tot_planck && d->n_t_plnk >= 2, "LW lookup: missing Planck tables");
-        // (kmajor, planck_fraction) interleaved: one 8-byte (Float32) load per interpolation corner
+    {   // kmajor (and planck_fraction): one 16-byte entry per (t, p, eta, g) that carries the neighbours ONE gather should
+        // bring (common.h DevGas::off_kmajor; device.h gas_issue reads them in this order)
+        RR_CHECK(d->is_sw || (d->planck_fraction && d->t_planck && d->tot_planck && d->n_t_plnk >= 2), "LW lookup: missing Planck tables");
         const FT *sk = (const FT *)d->kmajor, *sp = (const FT *)d->planck_fraction;
-        const size_t at = arena_piece((size_t)2 * NE * NP * NT * NG);
+        constexpr size_t NV = KMAJOR_ENTRY_BYTES / sizeof(FT);   // values per entry: 4 (Float32) or 2 (Float64)
+        const size_t at = arena_piece(NV * NE * NP * NT * NG);
         for (int64_t gq = 0; gq < NG; gq++)
             for (int64_t t = 0; t < NT; t++)
                 for (int64_t p = 0; p < NP; p++)
                     for (int64_t e = 0; e < NE; e++) {
-                        const size_t src = e + NE * (p + NP * (t + NT * gq)), dst = at + 2 * (((t * NP + p) * NE + e) * NG + gq);
-                        arena[dst] = sk[src];
-                        arena[dst + 1] = sp[src];
+                        const int64_t e1 = std::min(e + 1, NE - 1), p1 = std::min(p + 1, NP - 1);
+                        auto src = [&](int64_t ee, int64_t pp) { return (size_t)(ee + NE * (pp + NP * (t + NT * gq))); };
+                        FT *o = &arena[at + NV * (((t * NP + p) * NE + e) * NG + gq)];
+                        if (d->is_sw && NV == 4) { o[0] = sk[src(e, p)]; o[1] = sk[src(e1, p)]; o[2] = sk[src(e, p1)]; o[3] = sk[src(e1, p1)]; }
+                        else if (d->is_sw) { o[0] = sk[src(e, p)]; o[1] = sk[src(e1, p)]; }
+                        else if (NV == 4) { o[0] = sk[src(e, p)]; o[1] = sp[src(e, p)]; o[2] = sk[src(e1, p)]; o[3] = sp[src(e1, p)]; }
+                        else { o[0] = sk[src(e, p)]; o[1] = sp[src(e, p)]; }
                     }
         g.off_kmajor = (unsigned)(at * sizeof(FT));
+    }
+    if (!d->is_sw) {
         TRY(upload_raw<FT>(lk, d->t_planck, d->n_t_plnk, &g.t_planck));
         TRY(upload_raw<FT>(lk, d->tot_planck, d->n_t_plnk * NB, &g.tot_planck));
     }

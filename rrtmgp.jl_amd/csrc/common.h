@@ -34,7 +34,11 @@ struct DevGas {
     // the tables the g-point lanes gather from live in ONE allocation (one scalar base address for
     // every global_load of the hot loop); offsets in bytes:
     const char *arena;
-    unsigned off_kmajor;     // SW: [t][p][eta][gpt]; LW: [t][p][eta][gpt][2] = (kmajor, planck_fraction) pairs
+    // [t][p][eta][gpt] entries of KMAJOR_ENTRY_BYTES = 16: everything ONE gather per (T plane[, p plane]) corner needs.
+    //   LW Float32 {k(e), pf(e), k(e+1), pf(e+1)}   LW Float64 {k(e), pf(e)}          (pf = planck_fraction)
+    //   SW Float32 {k(e,p), k(e+1,p), k(e,p+1), k(e+1,p+1)}   SW Float64 {k(e), k(e+1)}
+    // (the neighbour of the last eta / p row repeats that row: the interpolation never starts there)
+    unsigned off_kmajor;
     unsigned off_kminor[2];  // [t][eta][contrib], contrib = koff[b] + ((i/4)*ng_b + (g - lo_b))*4 + i%4; region 0 lower, 1 upper
     unsigned off_rayl[2];    // [t][eta][gpt]   (SW)
     const FT *t_planck;    // [n_t_plnk]                  (LW)
@@ -109,6 +113,7 @@ struct DeviceBuffer {
 
 enum LookupKind { LK_GAS = 1, LK_CLOUD = 2, LK_AEROSOL = 3 };
 
+constexpr unsigned KMAJOR_ENTRY_BYTES = 16;
 constexpr int MINOR_GROUP = 4;  // minor-gas contributors fetched by one load per interpolation corner
 
 }  // namespace rrtmgp

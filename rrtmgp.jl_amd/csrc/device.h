@@ -903,7 +903,7 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     lb.m_pack = g0 | (n0 << 8) | (g1 << 16) | (n1 << 24);
     constexpr unsigned E = sizeof(FT);
     lb.gE = g * E;
-    lb.gk = lk.off_kmajor + g * (lk.is_sw ? E : 2 * E);
+    lb.gk = lk.off_kmajor + g * KMAJOR_ENTRY_BYTES;
     lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi * MINOR_GROUP) * E;
     lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi * MINOR_GROUP) * E;
     return lb;
@@ -946,7 +946,7 @@ struct GasLoads {
 template <typename FT, bool SW, int CHK>
 __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, const ColShared<FT, CHK> &sh, const LaneBand &lb,
                                                       int k, int kk) {
-    constexpr unsigned E = sizeof(FT), EK = SW ? E : 2 * E;  // LW: (kmajor, planck_fraction) pairs
+    constexpr unsigned E = sizeof(FT), EK = KMAJOR_ENTRY_BYTES;  // one 16-byte entry per (t, p, eta, g-point): common.h
     GasLoads<FT, SW> G;
     const LayerRec<FT> &L = sh.lay[k];
     const int li = L.idx;
@@ -968,23 +968,40 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     // the corner strides are wave-uniform: they go into the scalar base of the load, so that one VGPR
     // offset serves four loads
     const char *b0 = lk.arena, *b1 = lk.arena + sE, *b2 = lk.arena + sP, *b3 = lk.arena + sP + sE;
-    if (SW) {
-        G.k000 = ldg<FT>(b0, o1); G.k100 = ldg<FT>(b1, o1); G.k010 = ldg<FT>(b2, o1); G.k110 = ldg<FT>(b3, o1);
-        G.q000 = ldg<FT>(b0, o2); G.q100 = ldg<FT>(b1, o2); G.q010 = ldg<FT>(b2, o2); G.q110 = ldg<FT>(b3, o2);
-        G.p000 = G.p100 = G.p010 = G.p110 = G.r000 = G.r100 = G.r010 = G.r110 = FT(0);
-        // compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners, issued with the others
-        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
-        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
-        G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
-        G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
-    } else {
+    // The vector memory pipeline prices a gather by the instruction, not by the bytes: 8 cycles of the CU's texture
+    // addresser for a 4-byte one, 16 for 8 AND for 16 bytes per lane (tools/ubench/gather_l1.hip), and these kernels are
+    // bound by exactly that.  Every kmajor gather is therefore a 16-byte one: the table entry of (t, p, eta, g) also holds
+    // the neighbours along eta (and along p, SW Float32) that the interpolation reads with it (build_gas, common.h).
+    G.p000 = G.p100 = G.p010 = G.p110 = G.r000 = G.r100 = G.r010 = G.r110 = FT(0);
+    G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
+    if constexpr (SW && sizeof(FT) == 4) {          // {k(e, p), k(e+1, p), k(e, p+1), k(e+1, p+1)}: 2 gathers instead of 8
+        const V4<FT> a = ldg<V4<FT>>(b0, o1), e = ldg<V4<FT>>(b0, o2);
+        G.k000 = a.x; G.k100 = a.y; G.k010 = a.z; G.k110 = a.w;
+        G.q000 = e.x; G.q100 = e.y; G.q010 = e.z; G.q110 = e.w;
+    } else if constexpr (SW) {                      // {k(e), k(e+1)}: 4 instead of 8
+        const V2<FT> a = ldg<V2<FT>>(b0, o1), c = ldg<V2<FT>>(b2, o1), e = ldg<V2<FT>>(b0, o2), g = ldg<V2<FT>>(b2, o2);
+        G.k000 = a.x; G.k100 = a.y; G.k010 = c.x; G.k110 = c.y;
+        G.q000 = e.x; G.q100 = e.y; G.q010 = g.x; G.q110 = g.y;
+    } else if constexpr (sizeof(FT) == 4) {         // {k(e), pf(e), k(e+1), pf(e+1)}: 4 instead of 8
+        const V4<FT> a = ldg<V4<FT>>(b0, o1), c = ldg<V4<FT>>(b2, o1), e = ldg<V4<FT>>(b0, o2), g = ldg<V4<FT>>(b2, o2);
+        G.k000 = a.x; G.p000 = a.y; G.k100 = a.z; G.p100 = a.w;
+        G.k010 = c.x; G.p010 = c.y; G.k110 = c.z; G.p110 = c.w;
+        G.q000 = e.x; G.r000 = e.y; G.q100 = e.z; G.r100 = e.w;
+        G.q010 = g.x; G.r010 = g.y; G.q110 = g.z; G.r110 = g.w;
+    } else {                                        // {k, pf}: 8 gathers of 16 bytes
         const V2<FT> a = ldg<V2<FT>>(b0, o1), b = ldg<V2<FT>>(b1, o1);
         const V2<FT> c = ldg<V2<FT>>(b2, o1), d = ldg<V2<FT>>(b3, o1);
         const V2<FT> e = ldg<V2<FT>>(b0, o2), f = ldg<V2<FT>>(b1, o2);
         const V2<FT> g = ldg<V2<FT>>(b2, o2), h = ldg<V2<FT>>(b3, o2);
         G.k000 = a.x; G.k100 = b.x; G.k010 = c.x; G.k110 = d.x; G.q000 = e.x; G.q100 = f.x; G.q010 = g.x; G.q110 = h.x;
         G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
-        G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
+    }
+    if (SW) {
+        // compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners, issued with the others
+        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
+        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
+        G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
+        G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
     }
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
     // The contributors of a g-point sit in groups of MINOR_GROUP = 4 (build_gas): one 16-byte load per
@@ -1213,8 +1230,9 @@ struct Sweep {
     __device__ __forceinline__ void put(int lev, int a, FT v) const { *ptr(lev, a) = v; }
     __device__ __forceinline__ FT get(int lev, int a) const { return *ptr(lev, a); }
     // Three values of one level at once (a = 0, or 3 for the clear-sky twin): three rows, three 4-byte accesses per lane.
-    // ([level][lane][3] records, one 12-byte access per lane, were measured in round 3: fewer memory instructions, more
-    // VALU, slower — tools/experiments/README.md.)
+    // ([level][lane] records, one access per lane and level, were measured twice: 12-byte records in round 3, and 16-byte
+    // slots read with one 12-byte load in round 4 — written as 12 bytes or as the whole slot — 3.5 vs 4.1 M columns/s.
+    // Fewer memory instructions, yet slower: tools/experiments/README.md.)
     __device__ __forceinline__ void put3(int lev, int a, FT x, FT y, FT z) const {
         put(lev, a, x); put(lev, a + 1, y); put(lev, a + 2, z);
     }
