@@ -411,25 +411,31 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         // corner brings 4 contributors:   koff[b] + ((i / 4) * ng_b + (g - lo_b)) * 4 + i % 4
         // (a band with n_b contributors per g-point owns ceil(n_b / 4) groups; the padding entries are 0 and
         // carry a zero scaling).  The scalings of a layer are laid out the same way (slot = 4 * group + i % 4).
-        std::vector<int64_t> dst(std::max<int64_t>(m->n_contrib, 1), 0);
+        // SW: slot 0 of every band is the Rayleigh coefficient of this region (krayl[:, :, g], same (t, eta) rows, same
+        // interp2d weights; its "scaling" is the layer's (h2o + 1) col_dry): compute_tau_rayleigh rides in the first
+        // contributor group instead of costing four gathers of its own (RAYLEIGH_SLOT).
+        const int64_t lead = d->is_sw ? 1 : 0;
+        std::vector<int64_t> dst(std::max<int64_t>(m->n_contrib, 1), 0), rayl_dst(d->is_sw ? NG : 0, 0);
         std::vector<int> st4(NB, 0), slot_int;
         int64_t off = 0;
         for (int64_t b = 0; b < NB; b++) {
             const int64_t nb = bst[b + 1] - bst[b];
             RR_CHECK(nb >= 0, "minor bnd_st must be non-decreasing");
             // at least one group per band: a band without contributors reads its own all-zero group with zero scalings
-            const int64_t ngrp = std::max<int64_t>(1, (nb + MINOR_GROUP - 1) / MINOR_GROUP);
+            const int64_t ngrp = std::max<int64_t>(1, (nb + lead + MINOR_GROUP - 1) / MINOR_GROUP);
             koff[b] = (int)off;
             st4[b] = (int)slot_int.size();
-            for (int64_t i = 0; i < ngrp * MINOR_GROUP; i++) slot_int.push_back(i < nb ? (int)(bst[b] + i) : -1);
+            for (int64_t i = 0; i < ngrp * MINOR_GROUP; i++)
+                slot_int.push_back(i < lead ? RAYLEIGH_SLOT : i < nb + lead ? (int)(bst[b] + i - lead) : -1);
             lk->max_minor = std::max<int>(lk->max_minor, (int)nb);
             for (int64_t gi = 0; gi < ng[b]; gi++) {
                 const int64_t gq = lo[b] + gi;
                 RR_CHECK(m->gpt_st[gq + 1] - m->gpt_st[gq] == nb, "minor gpt_st inconsistent with bnd_st");
+                if (lead) rayl_dst[gq] = off + gi * MINOR_GROUP;
                 for (int64_t i = 0; i < nb; i++) {
-                    const int64_t src = m->gpt_st[gq] - 1 + i;
+                    const int64_t src = m->gpt_st[gq] - 1 + i, j = i + lead;
                     RR_CHECK(src >= 0 && src < m->n_contrib, "minor contributor index out of range");
-                    dst[src] = off + ((i / MINOR_GROUP) * ng[b] + gi) * MINOR_GROUP + i % MINOR_GROUP;
+                    dst[src] = off + ((j / MINOR_GROUP) * ng[b] + gi) * MINOR_GROUP + j % MINOR_GROUP;
                 }
             }
             off += ngrp * ng[b] * MINOR_GROUP;
@@ -447,15 +453,18 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         TRY(upload(lk, slot_int, &g.m_slot_int[r]));
         RR_CHECK(m->n_contrib == 0 || m->kminor, "minor lookup: missing kminor");
         TRY(relayout3(m->kminor, m->n_contrib, row, dst, &g.off_kminor[r]));
+        if (d->is_sw) {   // krayl (n_eta, n_t, n_gpt) of this region into the leading slots of the same rows
+            const FT *ry = (const FT *)(r == 0 ? d->rayl_lower : d->rayl_upper);
+            RR_CHECK(ry, "SW lookup: missing Rayleigh tables");
+            const size_t at = g.off_kminor[r] / sizeof(FT);
+            for (int64_t gq = 0; gq < NG; gq++)
+                for (int64_t t = 0; t < NT; t++)
+                    for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * row + rayl_dst[gq]] = ry[e + NE * (t + NT * gq)];
+        }
     }
-    g.off_rayl[0] = g.off_rayl[1] = 0;
     g.solar_src_scaled = nullptr;
     if (d->is_sw) {
-        RR_CHECK(d->rayl_lower && d->rayl_upper && d->solar_src_scaled, "SW lookup: missing Rayleigh / solar tables");
-        std::vector<int64_t> ident(NG);
-        for (int64_t i = 0; i < NG; i++) ident[i] = i;
-        TRY(relayout3(d->rayl_lower, NG, NG, ident, &g.off_rayl[0]));
-        TRY(relayout3(d->rayl_upper, NG, NG, ident, &g.off_rayl[1]));
+        RR_CHECK(d->solar_src_scaled, "SW lookup: missing solar source table");
         TRY(upload_raw<FT>(lk, d->solar_src_scaled, NG, &g.solar_src_scaled));
     }
     arena_piece(64);  // keeps the last table off the end of the allocation

@@ -39,8 +39,9 @@ struct DevGas {
     //   SW Float32 {k(e,p), k(e+1,p), k(e,p+1), k(e+1,p+1)}   SW Float64 {k(e), k(e+1)}
     // (the neighbour of the last eta / p row repeats that row: the interpolation never starts there)
     unsigned off_kmajor;
-    unsigned off_kminor[2];  // [t][eta][contrib], contrib = koff[b] + ((i/4)*ng_b + (g - lo_b))*4 + i%4; region 0 lower, 1 upper
-    unsigned off_rayl[2];    // [t][eta][gpt]   (SW)
+    // [t][eta][contrib], contrib = koff[b] + ((j/4)*ng_b + (g - lo_b))*4 + j%4; region 0 lower, 1 upper.  j = i for the LW
+    // lookup; SW: j = i + 1, and slot 0 holds the Rayleigh coefficient of the region (krayl) — RAYLEIGH_SLOT
+    unsigned off_kminor[2];
     const FT *t_planck;    // [n_t_plnk]                  (LW)
     const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
     const FT *ln_p_ref;    // [n_p_ref]
@@ -56,7 +57,7 @@ struct DevGas {
     const int *m_gasdata[2];  // (4, n_min_absrb)
     const int *m_koff[2];     // [n_bnd] offset of the band's block along the (padded) contributor axis
     const int *m_st4[2];      // [n_bnd] first scaling slot of the band (a multiple of MINOR_GROUP)
-    const int *m_slot_int[2]; // [m_nslot] gasdata column of each scaling slot, -1 for padding
+    const int *m_slot_int[2]; // [m_nslot] gasdata column of each scaling slot, -1 for padding, RAYLEIGH_SLOT for the Rayleigh slot (SW)
     int m_ncontrib[2];        // row length of kminor: padded contributors per (t, eta)
     int m_nint[2];            // minor intervals (gasdata columns) per region
     int m_nslot[2];           // scaling slots per region (every band padded to whole groups)
@@ -114,7 +115,8 @@ struct DeviceBuffer {
 enum LookupKind { LK_GAS = 1, LK_CLOUD = 2, LK_AEROSOL = 3 };
 
 constexpr unsigned KMAJOR_ENTRY_BYTES = 16;
-constexpr int MINOR_GROUP = 4;  // minor-gas contributors fetched by one load per interpolation corner
+constexpr int MINOR_GROUP = 4;
+constexpr int RAYLEIGH_SLOT = -2;  // m_slot_int value of the slot that carries krayl; its scaling is (h2o + 1) col_dry  // minor-gas contributors fetched by one load per interpolation corner
 
 }  // namespace rrtmgp
 

@@ -859,6 +859,7 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
         const int tropo = sh.lay[k].idx >> 16;
         FT scaling = FT(0);
         const int i = slot < (tropo ? lk.m_nslot[1] : lk.m_nslot[0]) ? (tropo ? lk.m_slot_int[1] : lk.m_slot_int[0])[slot] : -1;
+        if (i == RAYLEIGH_SLOT) scaling = sh.lay[k].ray_fac;   // compute_tau_rayleigh, gas_optics.jl:430-444
         if (i >= 0) {
             const int *gd = (tropo ? lk.m_gasdata[1] : lk.m_gasdata[0]) + 4 * i;
             const FT vmr_imnr = sh.vmr[gd[0] * nlay + k];
@@ -898,7 +899,9 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     lb.ibnd = lk.gpt2bnd[g];
     const int gi = g - lk.bnd_lo[lb.ibnd];
     lb.ngb = lk.bnd_ng[lb.ibnd];
-    const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - lk.m_bnd_st[0][lb.ibnd], n1 = lk.m_bnd_st[1][lb.ibnd + 1] - lk.m_bnd_st[1][lb.ibnd];
+    // slots of the band per region: its minor contributors, and in front of them the Rayleigh slot of a SW lookup
+    const int lead = lk.is_sw ? 1 : 0;
+    const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - lk.m_bnd_st[0][lb.ibnd] + lead, n1 = lk.m_bnd_st[1][lb.ibnd + 1] - lk.m_bnd_st[1][lb.ibnd] + lead;
     const int g0 = lk.m_st4[0][lb.ibnd] / MINOR_GROUP, g1 = lk.m_st4[1][lb.ibnd] / MINOR_GROUP;
     lb.m_pack = g0 | (n0 << 8) | (g1 << 16) | (n1 << 24);
     constexpr unsigned E = sizeof(FT);
@@ -933,10 +936,9 @@ template <typename FT, bool SW>
 struct GasLoads {
     FT k000, k100, k010, k110, q000, q100, q010, q110;   // kmajor corners (T plane 1: k, T plane 2: q)
     FT p000, p100, p010, p110, r000, r100, r010, r110;   // planck_fraction corners (LW)
-    FT y11, y21, y12, y22;                               // Rayleigh corners (SW)
     Corners<FT> g0, g1;                                  // minor-gas contributor groups
     V4<FT> s0, s1, wr, ar;                               // their scalings; (eta, T) weights; amount x pressure weights
-    FT fP, ray_fac;
+    FT fP;
     unsigned a1, a2, gstep, ncb;
     const FT *ms;
     int n;
@@ -952,7 +954,6 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     const int li = L.idx;
     const unsigned jT = li & 0xff, jP = (li >> 8) & 0xff, tropo = li >> 16;
     G.fP = L.fP;
-    G.ray_fac = SW ? L.ray_fac : FT(0);
     const int r = kk * NBMAX + lb.ibnd;
     const unsigned jep = sh.ch->je[r];
     const unsigned je1 = jep & 0xff, je2 = jep >> 8;
@@ -973,7 +974,6 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     // bound by exactly that.  Every kmajor gather is therefore a 16-byte one: the table entry of (t, p, eta, g) also holds
     // the neighbours along eta (and along p, SW Float32) that the interpolation reads with it (build_gas, common.h).
     G.p000 = G.p100 = G.p010 = G.p110 = G.r000 = G.r100 = G.r010 = G.r110 = FT(0);
-    G.y11 = G.y21 = G.y12 = G.y22 = FT(0);
     if constexpr (SW && sizeof(FT) == 4) {          // {k(e, p), k(e+1, p), k(e, p+1), k(e+1, p+1)}: 2 gathers instead of 8
         const V4<FT> a = ldg<V4<FT>>(b0, o1), e = ldg<V4<FT>>(b0, o2);
         G.k000 = a.x; G.k100 = a.y; G.k010 = a.z; G.k110 = a.w;
@@ -996,13 +996,8 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         G.k000 = a.x; G.k100 = b.x; G.k010 = c.x; G.k110 = d.x; G.q000 = e.x; G.q100 = f.x; G.q010 = g.x; G.q110 = h.x;
         G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
     }
-    if (SW) {
-        // compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners, issued with the others
-        const unsigned sR = NG * E, gr = (tropo ? lk.off_rayl[1] : lk.off_rayl[0]) + lb.gE;
-        const unsigned r1 = __umul24(jT * NE + je1, sR) + gr, r2 = __umul24((jT + 1) * NE + je2, sR) + gr;
-        G.y11 = ldg<FT>(lk.arena, r1); G.y21 = ldg<FT>(lk.arena, r1 + sR);
-        G.y12 = ldg<FT>(lk.arena, r2); G.y22 = ldg<FT>(lk.arena, r2 + sR);
-    }
+    // (compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners of krayl arrive in slot 0 of the first
+    // contributor group below, and (h2o + 1) col_dry as that slot's scaling)
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
     // The contributors of a g-point sit in groups of MINOR_GROUP = 4 (build_gas): one 16-byte load per
     // interpolation corner and one 16-byte LDS read of the 4 scalings serve a whole group.  The first group is
@@ -1050,21 +1045,25 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
     else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
     const FT w11 = G.wr.x, w21 = G.wr.y, w12 = G.wr.z, w22 = G.wr.w;
     FT tau_minor = FT(0);
-    auto consume = [&](const Corners<FT> &c, const V4<FT> &sc) {
-        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order
-        tau_minor += (w11 * c.c11.x + w21 * c.c21.x + w12 * c.c12.x + w22 * c.c22.x) * sc.x;
+    FT tau_ray = FT(0);
+    auto consume = [&](const Corners<FT> &c, const V4<FT> &sc, bool first) {
+        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order; the leading slot of a SW
+        // lookup is the Rayleigh coefficient, and that product is tau_rayleigh (gas_optics.jl:430-444)
+        const FT t0 = (w11 * c.c11.x + w21 * c.c21.x + w12 * c.c12.x + w22 * c.c22.x) * sc.x;
+        if (SW && first) tau_ray = t0;
+        else tau_minor += t0;
         tau_minor += (w11 * c.c11.y + w21 * c.c21.y + w12 * c.c12.y + w22 * c.c22.y) * sc.y;
         tau_minor += (w11 * c.c11.z + w21 * c.c21.z + w12 * c.c12.z + w22 * c.c22.z) * sc.z;
         tau_minor += (w11 * c.c11.w + w21 * c.c21.w + w12 * c.c12.w + w22 * c.c22.w) * sc.w;
     };
-    consume(G.g0, G.s0);
+    consume(G.g0, G.s0, true);
     if (G.two) {
-        consume(G.g1, G.s1);
+        consume(G.g1, G.s1, false);
         const char *kmn = lk.arena;
         for (int i0 = 2 * MINOR_GROUP; i0 < G.n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases (rare; exposed)
             const unsigned x1 = G.a1 + __umul24((unsigned)(i0 / MINOR_GROUP), G.gstep), x2 = x1 - G.a1 + G.a2;
             const Corners<FT> c{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + G.ncb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + G.ncb, x2)};
-            consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0));
+            consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0), false);
         }
     }
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
@@ -1078,8 +1077,6 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
         tau = m_max(tau_major + tau_minor, FT(0));
         ssa = FT(0);
     } else {
-        const FT kr = w11 * G.y11 + w21 * G.y21 + w12 * G.y12 + w22 * G.y22;
-        const FT tau_ray = kr * G.ray_fac;
         tau = m_max(tau_major + tau_minor + tau_ray, FT(0));
         ssa = tau_ray * m_rcp(tau);
         if (tau <= FT(0)) ssa = FT(0);
