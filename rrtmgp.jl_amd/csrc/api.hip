@@ -1001,16 +1001,28 @@ static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, con
     return as->ncol >= 16384;
 }
 
+// Streams are created only by the path that uses them: the runtime multiplexes a process's streams onto a few hardware
+// queues (4 by default), and a stream that merely EXISTS can put a workspace's copy stream on the queue of another
+// workspace's compute stream — the two-solve host leg (two workspaces) fell from 38 to 42-45 ms when every pipelined
+// workspace also owned the second compute lane of the short Layer-2 step (tools/experiments/host_regress_ab.sh).
+static int fork_join_events(rrtmgp_workspace *ws) {
+    for (int i = 0; i < 2; i++)
+        if (!ws->ev_k[i]) RR_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
+    return RRTMGP_OK;
+}
 static int pipeline_resources(rrtmgp_workspace *ws) {
     if (ws->copy_stream) return RRTMGP_OK;
     RR_HIP(hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking));
-    RR_HIP(hipStreamCreateWithFlags(&ws->alt_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-        RR_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
-        RR_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < 2; i++) RR_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
+    TRY(fork_join_events(ws));
     ws->stage_alt.resize(ws->stage.size());
     return RRTMGP_OK;
+}
+// second compute lane of a short Layer-2 step (step_t)
+static int lane_resources(rrtmgp_workspace *ws) {
+    if (ws->alt_stream) return RRTMGP_OK;
+    RR_HIP(hipStreamCreateWithFlags(&ws->alt_stream, hipStreamNonBlocking));
+    return fork_join_events(ws);
 }
 
 // `chunk(slice, n_columns, stager, vmr_is_gm)` stages and launches the columns [slice.c0, slice.c0 + n_columns)
@@ -1592,7 +1604,7 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
     static const int force_overlap = getenv("RRTMGP_HIP_STEP_OVERLAP") ? atoi(getenv("RRTMGP_HIP_STEP_OVERLAP")) : -1;
     const bool short_step = ncol <= 2 * (size_t)ws->n_cu || (ncol >= 16 * (size_t)ws->n_cu && ncol <= 48 * (size_t)ws->n_cu);
     const bool overlap = !(chunk && !st.packed) && (force_overlap >= 0 ? force_overlap != 0 : short_step);
-    if (overlap) TRY(pipeline_resources(ws));
+    if (overlap) TRY(lane_resources(ws));
     if (prep) TRY(launch_prepare<FT>(ws, pv, *a->params, *po, false));
     const uint64_t seed = opts ? opts->seed : 0;
     const int64_t coff = opts ? opts->col_offset : 0;
