@@ -139,6 +139,25 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def vmem_pipeline(k):
+    """Share of the dominant kernel's time that the CUs' vector memory pipelines are busy, from the profile's counters and
+    the per-instruction cost measured by tools/ubench/gather_l1.hip (profiles/r04_gather_l1_ubench.txt): a wave-wide
+    access of 4 bytes per lane holds a CU's pipeline for 8 cycles, one of 8-16 bytes for 16.5.  The 4-byte instructions
+    of these kernels are the sweep-scratch accesses: every store and as many loads; every other load is 16 bytes wide."""
+    need = ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "GRBM_GUI_ACTIVE", "avg_us")
+    if not all(k.get(c) for c in need):
+        return None
+    narrow = 2.0 * k["SQ_INSTS_VMEM_WR"]
+    wide = k["SQ_INSTS_VMEM_RD"] - k["SQ_INSTS_VMEM_WR"]
+    busy = 8.0 * narrow + 16.5 * wide                      # pipeline cycles, all CUs together
+    cycles = k["GRBM_GUI_ACTIVE"] / 8.0                    # the counter sums the 8 XCDs
+    n_cu = 256
+    return {"frac": busy / (n_cu * cycles), "busy_cycles_per_cu": busy / n_cu, "kernel_cycles": cycles,
+            "instructions_4_byte": narrow, "instructions_16_byte": wide, "profiled_kernel_ms": k["avg_us"] / 1e3,
+            "model": "8 cycles per 4-byte, 16.5 per 8..16-byte wave instruction (tools/ubench/gather_l1.hip); "
+                     "counters SQ_INSTS_VMEM_RD/WR, GRBM_GUI_ACTIVE of the profile named in roofline.traffic_source"}
+
+
 def run_l2(args):
     """The Layer-2 step on host arrays through the Python mirror of RRTMGPSolver (the Julia glue's update_fluxes! override
     makes the same library call): columns/s and the bytes that crossed PCIe per column, from the workspace's counters."""
@@ -403,6 +422,7 @@ def main():
         default_workload = (not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32"
                             and not args.host and args.clear_sky_diag == "off" and not noscat and clouds and not args.lw_only
                             and not strong)
+        vmem = None
         if os.path.exists(prof) and default_workload:
             # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
             # (tools/profile2.sh -> tools/rocprof_summary.py): (2 * FETCH_SIZE + WRITE_SIZE) KB, the factor 2
@@ -421,6 +441,7 @@ def main():
                 traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
                 traffic_source = {"profile": pj.get("source"), "git_sha": pj.get("git_sha"),
                                   "profiled_kernel_ms": k.get("avg_us", 0.0) / 1e3}
+                vmem = vmem_pipeline(k)
         out = {
             "metric": "columns/sec, all-sky LW+SW 2-stream (nlay=64, 256+224 gpt)",
             "value": value,
@@ -454,6 +475,8 @@ def main():
             "valu": {"achieved": valu_tflops, "peak": valu_peak, "unit": "TFLOP/s",
                      "frac": valu_tflops / valu_peak,
                      "algorithmic_flops_per_column": flops / ncol},
+            # the resource that does bind, from the same profile as `traffic`; null without it
+            "vmem_pipeline": vmem,
             "kernels": {"lw_solve_kernel_ms": ms_lw, "sw_solve_kernel_ms": ms_sw,
                         "lw_bytes_per_column": b_lw, "sw_bytes_per_column": b_sw, "step_bytes_per_column": b_step,
                         "timing": "HIP events by the library around each launch, mean of 3 steps after the timed region"},
