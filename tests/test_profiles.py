@@ -1,0 +1,47 @@
+"""The committed rocprofv3 summary that bench.py folds into its line (`profiles/latest.json`): it must belong to the kernel
+sources in the tree — bench.py withholds `roofline.traffic` and `vmem_pipeline` otherwise — and carry the counters both
+need.  CPU only: nothing here touches a GPU."""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _profile():
+    with open(os.path.join(ROOT, "profiles", "latest.json")) as fh:
+        return json.load(fh)
+
+
+def test_latest_profile_was_taken_on_the_kernel_sources_in_the_tree():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocprof_summary import kernel_source_sha256
+    pj = _profile()
+    assert pj["kernel_source_sha256"] == kernel_source_sha256(ROOT), \
+        "kernel sources changed after profiles/latest.json was taken: re-run tools/profile2.sh and commit its summary"
+    # the human-readable summary of the same run is committed next to it
+    assert os.path.exists(os.path.join(ROOT, "profiles", pj["source"].replace("prof_", "") + "_kernels.txt"))
+
+
+def test_profile_carries_the_counters_of_traffic_and_vmem_pipeline():
+    pj, bench = _profile(), _bench()
+    for name in ("lw_solve_kernel", "sw_solve_kernel"):
+        k = pj["kernels"][name]
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "GRBM_GUI_ACTIVE", "avg_us"):
+            assert k.get(c), (name, c)
+        v = bench.vmem_pipeline(k)
+        # a share of the kernel's time: positive, below 1, and the two instruction classes add up to the counters
+        assert 0.3 < v["frac"] < 1.0, v
+        assert v["instructions_4_byte"] + v["instructions_16_byte"] == k["SQ_INSTS_VMEM_RD"] + k["SQ_INSTS_VMEM_WR"]
+        # HBM-side bytes per launch stay far above the algorithmic 0.5 GB (the sweep scratch) and far below HBM's reach
+        traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        assert 2e10 < traffic < 2e11, traffic
+    assert bench.vmem_pipeline({"SQ_INSTS_VMEM_RD": 1.0}) is None   # an incomplete profile gives no number
