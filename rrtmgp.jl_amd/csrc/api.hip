@@ -319,16 +319,6 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         arena.resize(at + n, FT(0));
         return at;
     };
-    // (n_eta, n_t, n) -> [t][eta][row], element c of the source at position dst_of_src[c] < row (the rest stays 0)
-    auto relayout3 = [&](const void *src, int64_t n, int64_t row, const std::vector<int64_t> &dst_of_src, unsigned *off) -> int {
-        const FT *s = (const FT *)src;
-        const size_t at = arena_piece((size_t)NE * NT * row);
-        for (int64_t c = 0; c < n; c++)
-            for (int64_t t = 0; t < NT; t++)
-                for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * row + dst_of_src[c]] = s[e + NE * (t + NT * c)];
-        *off = (unsigned)(at * sizeof(FT));
-        return RRTMGP_OK;
-    };
     g.t_planck = nullptr; g.tot_planck = nullptr;
     {   // kmajor (and planck_fraction): one 16-byte entry per (t, p, eta, g) that carries the neighbours ONE gather should
         // bring (common.h DevGas::off_kmajor; device.h gas_issue reads them in this order)
@@ -397,6 +387,7 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
     TRY(upload(lk, lo, &g.bnd_lo));
     TRY(upload(lk, ng, &g.bnd_ng));
     const rrtmgp_minor_desc *md[2] = {&d->minor_lower, &d->minor_upper};
+    std::vector<int> slots[2] = {std::vector<int>(NB, 0), std::vector<int>(NB, 0)};  // slots per band and region (Rayleigh included)
     for (int r = 0; r < 2; r++) {
         const rrtmgp_minor_desc *m = md[r];
         RR_CHECK(m->bnd_st && m->gpt_st && (m->n_min_absrb == 0 || m->gasdata), "minor lookup: missing table");
@@ -406,61 +397,130 @@ static int build_gas(rrtmgp_lookup *lk, const rrtmgp_gas_lookup_desc *d, DevGas<
         for (int64_t i = 0; i < m->n_min_absrb; i++)
             RR_CHECK(gd[4 * i] >= 0 && gd[4 * i] < d->n_gases && gd[4 * i + 1] >= 0 && gd[4 * i + 1] < d->n_gases,
                      "minor gas index out of range");
-        // reference order: contributor (gpt_st[g] - 1) + i.  Device order: the contributors of a g-point come in
-        // groups of MINOR_GROUP = 4 that sit next to each other, so that ONE 16-byte (Float32) load per interpolation
-        // corner brings 4 contributors:   koff[b] + ((i / 4) * ng_b + (g - lo_b)) * 4 + i % 4
-        // (a band with n_b contributors per g-point owns ceil(n_b / 4) groups; the padding entries are 0 and
-        // carry a zero scaling).  The scalings of a layer are laid out the same way (slot = 4 * group + i % 4).
-        // SW: slot 0 of every band is the Rayleigh coefficient of this region (krayl[:, :, g], same (t, eta) rows, same
-        // interp2d weights; its "scaling" is the layer's (h2o + 1) col_dry): compute_tau_rayleigh rides in the first
-        // contributor group instead of costing four gathers of its own (RAYLEIGH_SLOT).
+        // reference order: contributor (gpt_st[g] - 1) + i.  Device order: the slots of a g-point (SW: slot 0 = the Rayleigh
+        // coefficient, then the contributors) come in PAIRS, and the 16-byte (Float32) entry of a pair at (t, eta) holds both
+        // slots at eta AND at eta + 1:   {c_2p(e), c_2p(e+1), c_2p+1(e), c_2p+1(e+1)}   at
+        //     koff[b] + (p * ng_b + (g - lo_b)) * 4        along the row of (t, eta)
+        // so that ONE gather per T plane serves two contributors (interp2d, optics_utils.jl:85-98, reads eta and eta + 1 of
+        // jT at jeta[1] and of jT + 1 at jeta[2]: two gathers per pair).  The vector memory pipeline prices a gather by the
+        // instruction (gas_issue, device.h); with 4 contributors x 1 corner per gather (rounds 2-4) a band with 1-2 slots paid
+        // 4 gathers and one with 5-6 paid 8, now 2 and 6.  A band with n_b slots owns max(1, ceil(n_b / 2)) pairs; padding
+        // entries are 0 and carry a zero scaling.  The scalings of a layer are laid out the same way (slot = 2 * pair + j % 2).
+        // SW: compute_tau_rayleigh rides in slot 0 (krayl[:, :, g] has the same (t, eta) rows and interp2d weights; its
+        // "scaling" is the layer's (h2o + 1) col_dry) instead of costing gathers of its own (RAYLEIGH_SLOT).
         const int64_t lead = d->is_sw ? 1 : 0;
         std::vector<int64_t> dst(std::max<int64_t>(m->n_contrib, 1), 0), rayl_dst(d->is_sw ? NG : 0, 0);
-        std::vector<int> st4(NB, 0), slot_int;
+        std::vector<int> st2(NB, 0), slot_int;
         int64_t off = 0;
         for (int64_t b = 0; b < NB; b++) {
             const int64_t nb = bst[b + 1] - bst[b];
             RR_CHECK(nb >= 0, "minor bnd_st must be non-decreasing");
-            // at least one group per band: a band without contributors reads its own all-zero group with zero scalings
-            const int64_t ngrp = std::max<int64_t>(1, (nb + lead + MINOR_GROUP - 1) / MINOR_GROUP);
+            // at least one pair per band: a band without contributors reads its own all-zero pair with zero scalings
+            const int64_t npair = std::max<int64_t>(1, (nb + lead + MINOR_PAIR - 1) / MINOR_PAIR);
             koff[b] = (int)off;
-            st4[b] = (int)slot_int.size();
-            for (int64_t i = 0; i < ngrp * MINOR_GROUP; i++)
+            st2[b] = (int)slot_int.size();
+            for (int64_t i = 0; i < npair * MINOR_PAIR; i++)
                 slot_int.push_back(i < lead ? RAYLEIGH_SLOT : i < nb + lead ? (int)(bst[b] + i - lead) : -1);
             lk->max_minor = std::max<int>(lk->max_minor, (int)nb);
+            slots[r][b] = (int)(nb + lead);
             for (int64_t gi = 0; gi < ng[b]; gi++) {
                 const int64_t gq = lo[b] + gi;
                 RR_CHECK(m->gpt_st[gq + 1] - m->gpt_st[gq] == nb, "minor gpt_st inconsistent with bnd_st");
-                if (lead) rayl_dst[gq] = off + gi * MINOR_GROUP;
+                // position of the slot's value AT ITS OWN eta inside the entry; the eta + 1 copy sits one element further
+                if (lead) rayl_dst[gq] = off + gi * MINOR_ENTRY;
                 for (int64_t i = 0; i < nb; i++) {
                     const int64_t src = m->gpt_st[gq] - 1 + i, j = i + lead;
                     RR_CHECK(src >= 0 && src < m->n_contrib, "minor contributor index out of range");
-                    dst[src] = off + ((j / MINOR_GROUP) * ng[b] + gi) * MINOR_GROUP + j % MINOR_GROUP;
+                    dst[src] = off + ((j / MINOR_PAIR) * ng[b] + gi) * MINOR_ENTRY + (j % MINOR_PAIR) * 2;
                 }
             }
-            off += ngrp * ng[b] * MINOR_GROUP;
+            off += npair * ng[b] * MINOR_ENTRY;
         }
         const int64_t row = off;
         g.m_ncontrib[r] = (int)row;
-        RR_CHECK(m->n_min_absrb <= 255 && slot_int.size() <= 1020, "more than 255 minor-gas intervals per region are not supported");
+        RR_CHECK(m->n_min_absrb <= 255 && slot_int.size() <= 510, "more than 255 minor-gas intervals per region are not supported");
         g.m_nint[r] = (int)m->n_min_absrb;
         g.m_nslot[r] = (int)slot_int.size();
         lk->max_int = std::max<int>(lk->max_int, (int)slot_int.size());
         TRY(upload(lk, bst, &g.m_bnd_st[r]));
         TRY(upload(lk, gd, &g.m_gasdata[r]));
         TRY(upload(lk, koff, &g.m_koff[r]));
-        TRY(upload(lk, st4, &g.m_st4[r]));
+        TRY(upload(lk, st2, &g.m_st2[r]));
         TRY(upload(lk, slot_int, &g.m_slot_int[r]));
         RR_CHECK(m->n_contrib == 0 || m->kminor, "minor lookup: missing kminor");
-        TRY(relayout3(m->kminor, m->n_contrib, row, dst, &g.off_kminor[r]));
-        if (d->is_sw) {   // krayl (n_eta, n_t, n_gpt) of this region into the leading slots of the same rows
-            const FT *ry = (const FT *)(r == 0 ? d->rayl_lower : d->rayl_upper);
-            RR_CHECK(ry, "SW lookup: missing Rayleigh tables");
-            const size_t at = g.off_kminor[r] / sizeof(FT);
-            for (int64_t gq = 0; gq < NG; gq++)
-                for (int64_t t = 0; t < NT; t++)
-                    for (int64_t e = 0; e < NE; e++) arena[at + (t * NE + e) * row + rayl_dst[gq]] = ry[e + NE * (t + NT * gq)];
+        {   // (n_eta, n_t, n) -> [t][eta][row]: source element c of (e, t) goes to its slot of row (t, e) and, as the eta + 1
+            // neighbour, to the element behind it in row (t, e - 1); the last eta row repeats itself (never a base row)
+            const size_t at = arena_piece((size_t)NE * NT * row);
+            auto put = [&](const FT *s, int64_t nsrc, const std::vector<int64_t> &where) {
+                for (int64_t c = 0; c < nsrc; c++)
+                    for (int64_t t = 0; t < NT; t++)
+                        for (int64_t e = 0; e < NE; e++) {
+                            const FT v = s[e + NE * (t + NT * c)];
+                            arena[at + (t * NE + e) * row + where[c]] = v;
+                            if (e > 0) arena[at + (t * NE + e - 1) * row + where[c] + 1] = v;
+                            if (e == NE - 1) arena[at + (t * NE + e) * row + where[c] + 1] = v;
+                        }
+            };
+            put((const FT *)m->kminor, m->n_contrib, dst);
+            if (d->is_sw) {   // krayl (n_eta, n_t, n_gpt) of this region into the leading slots of the same rows
+                const FT *ry = (const FT *)(r == 0 ? d->rayl_lower : d->rayl_upper);
+                RR_CHECK(ry, "SW lookup: missing Rayleigh tables");
+                put(ry, NG, rayl_dst);
+            }
+            g.off_kminor[r] = (unsigned)(at * sizeof(FT));
         }
+    }
+    {   // lane -> g-point of the broadband (not per-band) instances.  A wavefront issues the minor-gas gathers of its
+        // LARGEST band (gas_issue): with whole 16-g-point bands the bands are dealt to the wavefronts so that bands with
+        // many slots share wavefronts, minimising  sum over wavefronts of (max pairs, lower) + (max pairs, upper).  Which
+        // lane solves a g-point enters nothing but the (fixed) order of the g-point sums.  RRTMGP_HIP_BAND_ORDER=identity
+        // keeps the bands where the lookup has them.
+        std::vector<int> lane_g(256, -1);
+        for (int64_t i = 0; i < std::min<int64_t>(NG, 256); i++) lane_g[i] = (int)i;
+        bool whole = NG <= 256 && NB * 16 == NG;
+        for (int64_t b = 0; b < NB && whole; b++) whole = ng[b] == 16;
+        const char *ord = getenv("RRTMGP_HIP_BAND_ORDER");
+        if (whole && NB > 4 && !(ord && !strcmp(ord, "identity"))) {
+            auto pairs = [&](int r, int b) { return std::max(1, (slots[r][b] + MINOR_PAIR - 1) / MINOR_PAIR); };
+            auto cost = [&](const std::vector<int> &perm) {
+                int c = 0;
+                for (int64_t w = 0; w * 4 < NB; w++) {
+                    int m0 = 0, m1 = 0;
+                    for (int64_t i = w * 4; i < std::min<int64_t>(NB, w * 4 + 4); i++) { m0 = std::max(m0, pairs(0, perm[i])); m1 = std::max(m1, pairs(1, perm[i])); }
+                    c += m0 + m1;
+                }
+                return c;
+            };
+            std::vector<int> best(NB);
+            for (int64_t b = 0; b < NB; b++) best[b] = (int)b;
+            int cbest = cost(best);
+            // starts: the bands sorted by (lower, upper), by (upper, lower) and by their sum; then pairwise exchanges
+            for (int key = 0; key < 3; key++) {
+                std::vector<int> p(NB);
+                for (int64_t b = 0; b < NB; b++) p[b] = (int)b;
+                std::stable_sort(p.begin(), p.end(), [&](int x, int y) {
+                    const int x0 = pairs(0, x), x1 = pairs(1, x), y0 = pairs(0, y), y1 = pairs(1, y);
+                    if (key == 0) return x0 != y0 ? x0 > y0 : x1 > y1;
+                    if (key == 1) return x1 != y1 ? x1 > y1 : x0 > y0;
+                    return x0 + x1 > y0 + y1;
+                });
+                int c = cost(p);
+                for (bool moved = true; moved;) {
+                    moved = false;
+                    for (int64_t i = 0; i < NB; i++)
+                        for (int64_t j = i + 1; j < NB; j++) {
+                            if (i / 4 == j / 4) continue;
+                            std::swap(p[i], p[j]);
+                            const int c2 = cost(p);
+                            if (c2 < c) { c = c2; moved = true; } else std::swap(p[i], p[j]);
+                        }
+                }
+                if (c < cbest) { cbest = c; best = p; }
+            }
+            for (int64_t i = 0; i < NB; i++)
+                for (int q = 0; q < 16; q++) lane_g[i * 16 + q] = lo[best[i]] + q;
+        }
+        TRY(upload(lk, lane_g, &g.lane_gpt));
     }
     g.solar_src_scaled = nullptr;
     if (d->is_sw) {

@@ -30,6 +30,7 @@ struct DevGas {
     int band_rows;
     const int *band_row_lo;    // [n_bnd + 1] first row of each band
     const int *band_lane_gpt;  // [256] g-point (0-based) of each lane of that layout, -1 for padding
+    const int *lane_gpt;       // [256] the same for the broadband instances: whole bands dealt to the wavefronts by minor-gas slot count (build_gas)
     FT p_ref_tropo;
     // the tables the g-point lanes gather from live in ONE allocation (one scalar base address for
     // every global_load of the hot loop); offsets in bytes:
@@ -39,8 +40,9 @@ struct DevGas {
     //   SW Float32 {k(e,p), k(e+1,p), k(e,p+1), k(e+1,p+1)}   SW Float64 {k(e), k(e+1)}
     // (the neighbour of the last eta / p row repeats that row: the interpolation never starts there)
     unsigned off_kmajor;
-    // [t][eta][contrib], contrib = koff[b] + ((j/4)*ng_b + (g - lo_b))*4 + j%4; region 0 lower, 1 upper.  j = i for the LW
-    // lookup; SW: j = i + 1, and slot 0 holds the Rayleigh coefficient of the region (krayl) — RAYLEIGH_SLOT
+    // [t][eta][row] of 16-byte (Float32) entries {c_2p(e), c_2p(e+1), c_2p+1(e), c_2p+1(e+1)} at koff[b] + (p*ng_b + (g - lo_b))*4:
+    // slot pair p of the g-point at eta and eta + 1; region 0 lower, 1 upper.  Slot j = contributor i for the LW lookup;
+    // SW: j = i + 1, and slot 0 holds the Rayleigh coefficient of the region (krayl) — RAYLEIGH_SLOT
     unsigned off_kminor[2];
     const FT *t_planck;    // [n_t_plnk]                  (LW)
     const FT *tot_planck;  // [bnd][n_t_plnk]             (LW; = reference (n_t_plnk, n_bnd))
@@ -56,11 +58,11 @@ struct DevGas {
     const int *m_bnd_st[2];   // [n_bnd+1] 0-based start into gasdata columns
     const int *m_gasdata[2];  // (4, n_min_absrb)
     const int *m_koff[2];     // [n_bnd] offset of the band's block along the (padded) contributor axis
-    const int *m_st4[2];      // [n_bnd] first scaling slot of the band (a multiple of MINOR_GROUP)
+    const int *m_st2[2];      // [n_bnd] first scaling slot of the band (a multiple of MINOR_PAIR)
     const int *m_slot_int[2]; // [m_nslot] gasdata column of each scaling slot, -1 for padding, RAYLEIGH_SLOT for the Rayleigh slot (SW)
-    int m_ncontrib[2];        // row length of kminor: padded contributors per (t, eta)
+    int m_ncontrib[2];        // row length of kminor in elements: 4 per (band pair, g-point)
     int m_nint[2];            // minor intervals (gasdata columns) per region
-    int m_nslot[2];           // scaling slots per region (every band padded to whole groups)
+    int m_nslot[2];           // scaling slots per region (every band padded to whole pairs)
     const FT *solar_src_scaled;  // [n_gpt]         (SW)
 };
 
@@ -115,8 +117,9 @@ struct DeviceBuffer {
 enum LookupKind { LK_GAS = 1, LK_CLOUD = 2, LK_AEROSOL = 3 };
 
 constexpr unsigned KMAJOR_ENTRY_BYTES = 16;
-constexpr int MINOR_GROUP = 4;
-constexpr int RAYLEIGH_SLOT = -2;  // m_slot_int value of the slot that carries krayl; its scaling is (h2o + 1) col_dry  // minor-gas contributors fetched by one load per interpolation corner
+constexpr int MINOR_PAIR = 2;    // minor-gas slots served by one gather per T plane
+constexpr int MINOR_ENTRY = 4;   // elements of a kminor entry: MINOR_PAIR slots x (eta, eta + 1)
+constexpr int RAYLEIGH_SLOT = -2;  // m_slot_int value of the slot that carries krayl; its scaling is (h2o + 1) col_dry
 
 }  // namespace rrtmgp
 

@@ -340,7 +340,7 @@ __device__ __forceinline__ void wave_sum16(const FT (&v)[16], FT (&w)[4]) {
 struct ColDims {
     int nlay, nlev, ngas1 /* rows of the gas table */, nwaves, nbnd;
     int lw, twostream, has_cld, has_aero, n_acc /* accumulated flux components per level */;
-    int max_int; /* minor-gas scaling slots per layer row (the larger region's; a multiple of MINOR_GROUP) */
+    int max_int; /* minor-gas scaling slots per layer row (the larger region's; a multiple of MINOR_PAIR) */
     int nseg;    /* flux accumulator segments per block: nwaves, or 4 per wave with per-band fluxes */
     int diag;    /* clear-sky fluxes are carried next to the all-sky ones (n_acc doubles) */
     /* sizes of the small lookup tables mirrored in LDS (TabCache) */
@@ -399,7 +399,7 @@ struct ColShared {
     LevelRec<FT> *lev;   // [nlev]
     FT *vmr;             // [ngas1][nlay]; row 0 is 1 (get_vmr ig == 0, VolumeMixingRatios.jl:97-99)
     int mscale_row;      // = max_int
-    FT *mscale;          // [CH][max_int] minor-gas scalings of the current chunk, slot-contiguous per layer (16-byte groups)
+    FT *mscale;          // [CH][max_int] minor-gas scalings of the current chunk, slot-contiguous per layer (pairs of slots)
     FT *acc;             // [nseg][nlev][n_acc]
     int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
     FT *miscf;           // [0]: pl_sfc_f
@@ -431,7 +431,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base
     s.lev = carve<LevelRec<FT>>(p, d.nlev);
     s.vmr = carve<FT>(p, (size_t)d.ngas1 * d.nlay);
     s.mscale_row = d.max_int;
-    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_GROUP) * CHK);
+    s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_PAIR) * CHK);
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
     s.misc = carve<int>(p, d.nwaves + 4);
     s.miscf = carve<FT>(p, 4);
@@ -883,11 +883,12 @@ __device__ inline void prepare_chunk(const ColShared<FT, CHK> &sh, const ColDims
 // (explicit lower/upper members: arrays indexed by the run-time region would live in scratch memory)
 struct LaneBand {
     int g, ibnd, ngb;
-    int m_pack;          // g0 | n0 << 8 | g1 << 16 | n1 << 24   (first scaling GROUP of the band / contributor count, per region)
+    int m_pack;          // p0 | n0 << 8 | p1 << 16 | n1 << 24   (first scaling PAIR of the band / slot count, per region)
+    int npw0, npw1;      // wave-uniform: slot pairs of the wavefront's largest band, per region (>= 1)
     unsigned gk;         // arena byte offset of this lane's g-point in the kmajor table
-    unsigned gm0, gm1;   // ... of this lane's first contributor group in kminor lower / upper
+    unsigned gm0, gm1;   // ... of this lane's first slot pair in kminor lower / upper
     unsigned gE;         // g * sizeof(FT)
-    __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }  // first group
+    __device__ __forceinline__ int m_st(unsigned tropo) const { return (m_pack >> (tropo ? 16 : 0)) & 0xff; }  // first pair
     __device__ __forceinline__ int m_n(unsigned tropo) const { return (m_pack >> (tropo ? 24 : 8)) & 0xff; }
     __device__ __forceinline__ unsigned gm(unsigned tropo) const { return tropo ? gm1 : gm0; }
 };
@@ -902,13 +903,19 @@ __device__ __forceinline__ LaneBand lane_band(const DevGas<FT> &lk, int g) {
     // slots of the band per region: its minor contributors, and in front of them the Rayleigh slot of a SW lookup
     const int lead = lk.is_sw ? 1 : 0;
     const int n0 = lk.m_bnd_st[0][lb.ibnd + 1] - lk.m_bnd_st[0][lb.ibnd] + lead, n1 = lk.m_bnd_st[1][lb.ibnd + 1] - lk.m_bnd_st[1][lb.ibnd] + lead;
-    const int g0 = lk.m_st4[0][lb.ibnd] / MINOR_GROUP, g1 = lk.m_st4[1][lb.ibnd] / MINOR_GROUP;
-    lb.m_pack = g0 | (n0 << 8) | (g1 << 16) | (n1 << 24);
+    const int p0 = lk.m_st2[0][lb.ibnd] / MINOR_PAIR, p1 = lk.m_st2[1][lb.ibnd] / MINOR_PAIR;
+    lb.m_pack = p0 | (n0 << 8) | (p1 << 16) | (n1 << 24);
+    // the gathers of a layer are issued for the wavefront's largest band (a gather costs the same with 16 lanes active)
+    int w0 = 1, w1 = 1;
+    while (__any(n0 > w0 * MINOR_PAIR)) w0++;
+    while (__any(n1 > w1 * MINOR_PAIR)) w1++;
+    lb.npw0 = __builtin_amdgcn_readfirstlane(w0);
+    lb.npw1 = __builtin_amdgcn_readfirstlane(w1);
     constexpr unsigned E = sizeof(FT);
     lb.gE = g * E;
     lb.gk = lk.off_kmajor + g * KMAJOR_ENTRY_BYTES;
-    lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi * MINOR_GROUP) * E;
-    lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi * MINOR_GROUP) * E;
+    lb.gm0 = lk.off_kminor[0] + (lk.m_koff[0][lb.ibnd] + gi * MINOR_ENTRY) * E;
+    lb.gm1 = lk.off_kminor[1] + (lk.m_koff[1][lb.ibnd] + gi * MINOR_ENTRY) * E;
     return lb;
 }
 
@@ -929,20 +936,21 @@ struct alignas(2 * sizeof(FT)) V2 {
 //   gas_issue  : LDS records -> gather addresses -> every gather of the layer in flight; nothing is consumed;
 //   gas_finish : ONE wait, then the interpolations.
 template <typename FT>
-struct Corners {
-    V4<FT> c11, c21, c12, c22;
+struct SlotPair {       // one kminor entry per T plane: {c_2p(e), c_2p(e+1), c_2p+1(e), c_2p+1(e+1)} at (jT, jeta1) and (jT + 1, jeta2)
+    V4<FT> a, b;
 };
+constexpr int MINOR_PAIRS_AHEAD = 4;   // slot pairs gathered ahead of the layer's single wait; bands with more than 8 slots loop
 template <typename FT, bool SW>
 struct GasLoads {
     FT k000, k100, k010, k110, q000, q100, q010, q110;   // kmajor corners (T plane 1: k, T plane 2: q)
     FT p000, p100, p010, p110, r000, r100, r010, r110;   // planck_fraction corners (LW)
-    Corners<FT> g0, g1;                                  // minor-gas contributor groups
-    V4<FT> s0, s1, wr, ar;                               // their scalings; (eta, T) weights; amount x pressure weights
+    SlotPair<FT> g0, g1, g2, g3;                         // minor-gas slot pairs (g1..g3 only when the wavefront has them)
+    V2<FT> s0, s1, s2, s3;                               // their scalings
+    V4<FT> wr, ar;                                       // (eta, T) weights; amount x pressure weights
     FT fP;
-    unsigned a1, a2, gstep, ncb;
+    unsigned a1, a2, gstep;
     const FT *ms;
-    int n;
-    bool two;
+    int n, npw;
 };
 
 template <typename FT, bool SW, int CHK>
@@ -999,37 +1007,34 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
     // (compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners of krayl arrive in slot 0 of the first
     // contributor group below, and (h2o + 1) col_dry as that slot's scaling)
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
-    // The contributors of a g-point sit in groups of MINOR_GROUP = 4 (build_gas): one 16-byte load per
-    // interpolation corner and one 16-byte LDS read of the 4 scalings serve a whole group.  The first group is
-    // loaded UNCONDITIONALLY, right behind the kmajor corners: no exec masking.  Padding entries (a band without minor
-    // gases owns one all-padding group) are 0 in the table and carry a zero scaling, which leaves the in-order sum
-    // unchanged.  When some band of this wavefront has a second group (5-8 contributors) in this region, its loads
-    // are issued too; lanes of the other bands re-read their first group with zero scalings.
+    // The slots of a g-point sit in pairs, and a kminor entry holds a pair at eta and eta + 1 (build_gas): one 16-byte
+    // gather per T plane and one 8-byte LDS read of the 2 scalings serve two contributors.  The first pair is loaded
+    // UNCONDITIONALLY, right behind the kmajor corners: no exec masking.  Padding entries (a band without minor gases owns
+    // one all-padding pair) are 0 in the table and carry a zero scaling, which leaves the in-order sum unchanged.  Further
+    // pairs are issued as far as the LARGEST band of this wavefront has them in this region (wave-uniform branches; lanes
+    // of smaller bands re-read their first pair with zero scalings).
     G.n = lb.m_n(tropo);
+    G.npw = tropo ? lb.npw1 : lb.npw0;
     const char *kmn = lk.arena;
     const unsigned NCb = (tropo ? lk.m_ncontrib[1] : lk.m_ncontrib[0]) * E;
     G.a1 = __umul24(jT * NE + je1, NCb) + lb.gm(tropo);
     G.a2 = __umul24((jT + 1) * NE + je2, NCb) + lb.gm(tropo);
-    G.gstep = lb.ngb * (MINOR_GROUP * E);  // byte distance between the groups of one g-point
-    G.ncb = NCb;
-    G.ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_GROUP;
-    auto corners = [&](unsigned x1, unsigned x2) {
-        return Corners<FT>{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + NCb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + NCb, x2)};
+    G.gstep = lb.ngb * (MINOR_ENTRY * E);  // byte distance between the pairs of one g-point
+    G.ms = sh.mscale + kk * sh.mscale_row + lb.m_st(tropo) * MINOR_PAIR;
+    const V2<FT> z2{FT(0), FT(0)};
+    // g1..g3 / s1..s3 stay unset unless loaded (gas_finish reads them under the same wave-uniform conditions)
+    G.g0 = SlotPair<FT>{ldg<V4<FT>>(kmn, G.a1), ldg<V4<FT>>(kmn, G.a2)};
+    G.s0 = *reinterpret_cast<const V2<FT> *>(G.ms);
+    auto further = [&](int p, SlotPair<FT> &gp, V2<FT> &sp) {
+        const bool mine = G.n > p * MINOR_PAIR;
+        const unsigned c = mine ? p * G.gstep : 0u;
+        gp = SlotPair<FT>{ldg<V4<FT>>(kmn, G.a1 + c), ldg<V4<FT>>(kmn, G.a2 + c)};
+        sp = *reinterpret_cast<const V2<FT> *>(G.ms + (mine ? p * MINOR_PAIR : 0));
+        if (!mine) sp = z2;
     };
-    const V4<FT> z4{FT(0), FT(0), FT(0), FT(0)};
-    // g1 / s1 stay unset unless the second group is loaded (gas_finish reads them under the same wave-uniform flag):
-    // zero-filling them costs 20 v_mov per layer, and invites the compiler to run the second group's 20 FMAs always
-    G.two = false;
-    G.g0 = corners(G.a1, G.a2);
-    G.s0 = *reinterpret_cast<const V4<FT> *>(G.ms);
-    G.two = __any(G.n > MINOR_GROUP);
-    if (G.two) {
-        const bool mine = G.n > MINOR_GROUP;
-        const unsigned c = mine ? G.gstep : 0u;
-        G.g1 = corners(G.a1 + c, G.a2 + c);
-        G.s1 = *reinterpret_cast<const V4<FT> *>(G.ms + (mine ? MINOR_GROUP : 0));
-        if (!mine) G.s1 = z4;
-    }
+    if (G.npw > 1) further(1, G.g1, G.s1);
+    if (G.npw > 2) further(2, G.g2, G.s2);
+    if (G.npw > 3) further(3, G.g3, G.s3);
     return G;
 }
 
@@ -1046,24 +1051,24 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
     const FT w11 = G.wr.x, w21 = G.wr.y, w12 = G.wr.z, w22 = G.wr.w;
     FT tau_minor = FT(0);
     FT tau_ray = FT(0);
-    auto consume = [&](const Corners<FT> &c, const V4<FT> &sc, bool first) {
-        // interp2d, optics_utils.jl:85-98, contributor by contributor in the reference's order; the leading slot of a SW
-        // lookup is the Rayleigh coefficient, and that product is tau_rayleigh (gas_optics.jl:430-444)
-        const FT t0 = (w11 * c.c11.x + w21 * c.c21.x + w12 * c.c12.x + w22 * c.c22.x) * sc.x;
+    auto consume = [&](const SlotPair<FT> &c, const V2<FT> &sc, bool first) {
+        // interp2d, optics_utils.jl:85-98, slot by slot in the reference's order; the leading slot of a SW lookup is the
+        // Rayleigh coefficient, and that product is tau_rayleigh (gas_optics.jl:430-444)
+        const FT t0 = (w11 * c.a.x + w21 * c.a.y + w12 * c.b.x + w22 * c.b.y) * sc.x;
         if (SW && first) tau_ray = t0;
         else tau_minor += t0;
-        tau_minor += (w11 * c.c11.y + w21 * c.c21.y + w12 * c.c12.y + w22 * c.c22.y) * sc.y;
-        tau_minor += (w11 * c.c11.z + w21 * c.c21.z + w12 * c.c12.z + w22 * c.c22.z) * sc.z;
-        tau_minor += (w11 * c.c11.w + w21 * c.c21.w + w12 * c.c12.w + w22 * c.c22.w) * sc.w;
+        tau_minor += (w11 * c.a.z + w21 * c.a.w + w12 * c.b.z + w22 * c.b.w) * sc.y;
     };
     consume(G.g0, G.s0, true);
-    if (G.two) {
-        consume(G.g1, G.s1, false);
+    if (G.npw > 1) consume(G.g1, G.s1, false);
+    if (G.npw > 2) consume(G.g2, G.s2, false);
+    if (G.npw > 3) consume(G.g3, G.s3, false);
+    if (G.npw > MINOR_PAIRS_AHEAD) {   // bands with more than 8 slots (rare; exposed)
         const char *kmn = lk.arena;
-        for (int i0 = 2 * MINOR_GROUP; i0 < G.n; i0 += MINOR_GROUP) {  // bands with more than 8 minor gases (rare; exposed)
-            const unsigned x1 = G.a1 + __umul24((unsigned)(i0 / MINOR_GROUP), G.gstep), x2 = x1 - G.a1 + G.a2;
-            const Corners<FT> c{ldg<V4<FT>>(kmn, x1), ldg<V4<FT>>(kmn + G.ncb, x1), ldg<V4<FT>>(kmn, x2), ldg<V4<FT>>(kmn + G.ncb, x2)};
-            consume(c, *reinterpret_cast<const V4<FT> *>(G.ms + i0), false);
+        for (int p = MINOR_PAIRS_AHEAD; p * MINOR_PAIR < G.n; p++) {
+            const unsigned c = __umul24((unsigned)p, G.gstep);
+            const SlotPair<FT> e{ldg<V4<FT>>(kmn, G.a1 + c), ldg<V4<FT>>(kmn, G.a2 + c)};
+            consume(e, *reinterpret_cast<const V2<FT> *>(G.ms + p * MINOR_PAIR), false);
         }
     }
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:

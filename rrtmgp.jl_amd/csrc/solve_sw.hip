@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // lane -> g-point: the identity, or (per-band fluxes) the band-by-band layout on 16-lane rows
-    const int gl = BAND ? a.lk.band_lane_gpt[tid] : (tid < a.lk.n_gpt ? tid : -1);
+    // lane -> g-point: whole bands dealt to the wavefronts by minor-gas slot count (build_gas: lane_gpt; the identity for
+    // ragged bands), or (per-band fluxes) the band-by-band layout on 16-lane rows
+    const int gl = BAND ? a.lk.band_lane_gpt[tid] : a.lk.lane_gpt[tid];
     const bool active = gl >= 0;
     const int g = active ? gl : a.lk.n_gpt - 1;
     const LaneBand lb = lane_band(a.lk, g);
