@@ -135,6 +135,30 @@ def test_partial_cloud_fraction_masks_match(tables64):
         np.testing.assert_array_equal(as_.cloud_state.cld_cover_sw, cref)
 
 
+def test_minor_gas_slot_pairs_and_bands_dealt_to_wavefronts(monkeypatch):
+    """kminor travels in slot pairs (one gather per T plane serves two contributors) and, with whole 16-g-point bands, the
+    bands are dealt to the wavefronts by slot count (csrc/api.hip build_gas).  Bands with 0 slots, odd counts and more than
+    8 slots (the pairs beyond the four gathered ahead of the wait) against the oracle, and the dealt order against the
+    lookup's own order: which lane solves a g-point enters only the order of the g-point sums."""
+    lw = S.make_gas_lookup("lw", np.float64, seed=3, n_bnd=9, gpt_per_bnd=16, n_minor_lower=(0, 11), n_minor_upper=(0, 7))
+    sw = S.make_gas_lookup("sw", np.float64, seed=5, n_bnd=7, gpt_per_bnd=16, n_minor_lower=(0, 11), n_minor_upper=(0, 7))
+    for lk in (lw, sw):
+        n = np.diff(np.asarray(lk.minor_lower.bnd_st))
+        assert n.min() == 0 and n.max() > 8 and (n % 2 == 1).any()
+    cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, seed=3), S.make_cloud_lookup("sw", sw.n_bnd, seed=3)
+    as_, lb, sb = S.make_columns(11, 40, np.float64, seed=17, random_cld_frac=True, cos_zenith=0.7, n_bnd_lw=lw.n_bnd, n_bnd_sw=sw.n_bnd)
+    ref_lw, ref_sw = O.solve_lw(as_, lb, lw, cl, seed=5), O.solve_sw(as_, sb, sw, cs, seed=5)
+    outs = {}
+    for order in ("dealt", "identity"):
+        monkeypatch.setenv("RRTMGP_HIP_BAND_ORDER", order)   # read when the lookup is uploaded
+        dlw, dsw = rte.DeviceLookup(lw), rte.DeviceLookup(sw)
+        outs[order] = (hip_lw(as_, lb, dlw, cl, seed=5), hip_sw(as_, sb, dsw, cs, seed=5))
+        assert maxdiff(outs[order][0], ref_lw, LWN) < 1e-8
+        assert maxdiff(outs[order][1], ref_sw, SWN) < 1e-8
+    assert maxdiff(outs["dealt"][0], outs["identity"][0], LWN) < 1e-10
+    assert maxdiff(outs["dealt"][1], outs["identity"][1], SWN) < 1e-10
+
+
 @pytest.mark.parametrize("nlay", [129, 150, 200])
 def test_deep_columns_with_clouds(tables64, nlay):
     """More than 128 layers with clouds: the McICA mask no longer fits two 64-bit registers per g-point; its words live
