@@ -1032,9 +1032,13 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         sp = *reinterpret_cast<const V2<FT> *>(G.ms + (mine ? p * MINOR_PAIR : 0));
         if (!mine) sp = z2;
     };
-    if (G.npw > 1) further(1, G.g1, G.s1);
-    if (G.npw > 2) further(2, G.g2, G.s2);
-    if (G.npw > 3) further(3, G.g3, G.s3);
+    if (G.npw > 1) {   // nested: a wavefront whose bands have one pair evaluates one branch, not three
+        further(1, G.g1, G.s1);
+        if (G.npw > 2) {
+            further(2, G.g2, G.s2);
+            if (G.npw > 3) further(3, G.g3, G.s3);
+        }
+    }
     return G;
 }
 
@@ -1060,15 +1064,21 @@ __device__ __forceinline__ void gas_finish(const DevGas<FT> &lk, const GasLoads<
         tau_minor += (w11 * c.a.z + w21 * c.a.w + w12 * c.b.z + w22 * c.b.w) * sc.y;
     };
     consume(G.g0, G.s0, true);
-    if (G.npw > 1) consume(G.g1, G.s1, false);
-    if (G.npw > 2) consume(G.g2, G.s2, false);
-    if (G.npw > 3) consume(G.g3, G.s3, false);
-    if (G.npw > MINOR_PAIRS_AHEAD) {   // bands with more than 8 slots (rare; exposed)
-        const char *kmn = lk.arena;
-        for (int p = MINOR_PAIRS_AHEAD; p * MINOR_PAIR < G.n; p++) {
-            const unsigned c = __umul24((unsigned)p, G.gstep);
-            const SlotPair<FT> e{ldg<V4<FT>>(kmn, G.a1 + c), ldg<V4<FT>>(kmn, G.a2 + c)};
-            consume(e, *reinterpret_cast<const V2<FT> *>(G.ms + p * MINOR_PAIR), false);
+    if (G.npw > 1) {
+        consume(G.g1, G.s1, false);
+        if (G.npw > 2) {
+            consume(G.g2, G.s2, false);
+            if (G.npw > 3) {
+                consume(G.g3, G.s3, false);
+                if (G.npw > MINOR_PAIRS_AHEAD) {   // bands with more than 8 slots (rare; exposed)
+                    const char *kmn = lk.arena;
+                    for (int p = MINOR_PAIRS_AHEAD; p * MINOR_PAIR < G.n; p++) {
+                        const unsigned c = __umul24((unsigned)p, G.gstep);
+                        const SlotPair<FT> e{ldg<V4<FT>>(kmn, G.a1 + c), ldg<V4<FT>>(kmn, G.a2 + c)};
+                        consume(e, *reinterpret_cast<const V2<FT> *>(G.ms + p * MINOR_PAIR), false);
+                    }
+                }
+            }
         }
     }
     // interp3d (optics_utils.jl:136-181) with the (eta, T) products and the column-amount x pressure products hoisted:
