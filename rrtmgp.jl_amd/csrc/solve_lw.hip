@@ -161,237 +161,242 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
 
-        if constexpr (!DIAG) {
-            // ---- bottom-up: optics + sources, and one layer behind them coefficients + adding
-            //      (compute_optical_props.jl:163-198, longwave_2stream.jl:273-302).  Per level the
-            //      sweep keeps A, B, albedo; src_k only enters U_k = albedo_k F_k + src_k additively,
-            //      so its g-point sum is taken here instead of being stored. ----
-            MaskWalk<true> mw(m0, m1, nlay, sh.mask);
-            FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);   // optics of layer k-1
-            FT lev_src_bot = FT(0), inc_prev = FT(0);         // lev_source[k-1], B(t_lev[k]) * pfrac[k-1]
-            FT albedo = FT(1) - emis, src = FT(0);
-            auto add_layer = [&](int kl, FT lev_src_top) {   // layer kl between levels kl and kl+1
-                FT Rdif, Tdif, src_up, src_dn;
-                lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_src_bot, lev_src_top, Rdif, Tdif, src_up, src_dn);
-                const FT denom = m_rcp(FT(1) - Rdif * albedo);  // Eq 10
-                sw.put3(kl, 0, Tdif * denom /* A */, (Rdif * src + src_dn) * denom /* B */, albedo);
-                const FT ss = seg_sum<BAND>(src * amask);
-                if (writer) acc[kl * NA] = ss;
-                const FT alb_n = Rdif + Tdif * Tdif * albedo * denom;  // Eq 9
-                src = src_up + Tdif * denom * (src + albedo * src_dn);   // Eq 11
-                albedo = alb_n;
-            };
-            for (int c = 0; c < nchunk; c++) {
-                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
-                mw.refill(k0);
-                __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                __syncthreads();
-                for (int kk = 0; kk < kn; kk++) {
-                    const int k = k0 + kk;
-                    FT tau, ssa, gg, pfrac;
+        // ---- sweep 1, TOP-DOWN: optics + sources, and one layer behind them coefficients + adding
+        //      (compute_optical_props.jl:163-198, longwave_2stream.jl:273-333).  The reference adds from the surface up
+        //      (albedo / source of everything below a level, Eqs 9-11) and then sweeps down.  The same layer relations
+        //     U_{k+1} = T U_k + R D_{k+1} + S_up ,   D_k = T D_{k+1} + R U_k + S_dn
+        // are closed here from the top instead, as sw_solve_kernel does: D_k = beta_k U_k + delta_k with beta = 0 and
+        // delta = inc_flux at the top of the domain,
+        //     den = 1 / (1 - beta_{k+1} R),  beta_k = R + T^2 beta_{k+1} den,
+        //     delta_k = S_dn + T den (delta_{k+1} + beta_{k+1} S_up)
+        // (the mirror image of Eqs 9-11; same fluxes), followed by the surface relation and one bottom-up sweep
+        //     U_{k+1} = A U_k + B,  D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1};   A = T den, B = (R delta + S_up) den.
+        // Per level the sweep keeps A, B, beta_{k+1}; delta only enters D additively, so its g-point sum is taken on the fly.
+        // What the closure from the top buys is everything ABOVE the column's highest cloudy layer (k > k2):
+        //   * gas-only longwave layers do not scatter (ssa = 0: R = 0 exactly), so beta stays 0 up there: D = delta is
+        //     complete after this sweep, den = 1, and the second sweep needs only A = T and B = S_up - TWO stored values
+        //     and one g-point sum per level instead of three and two (LW 15.0 -> 13.7 ms; aerosols scatter, so with them
+        //     k2 is the top layer and nothing changes);
+        //   * DIAG: above the highest cloudy layer the clear-sky twin IS the all-sky stream - same optics, same sources,
+        //     the same boundary above: no coefficients, no adding step, no scratch rows of its own (the second sweep reads
+        //     the all-sky rows for both).  Closed from the surface the two differ from the LOWEST cloudy layer up.
+        // The optics run one layer ahead of the adding step, whose lower level source sqrt(inc[k-1] dec[k]) needs the Planck
+        // fraction of the layer below. ----
+        struct Stream { FT beta, delta; };
+        Stream S{FT(0), inc}, C{FT(0), inc};
+        MaskWalk<false> mw(m0, m1, nlay, sh.mask);
+        {
+            const FT sd = seg_sum<BAND>(inc * amask);
+            if (writer) { acc[nlay * NA + 1] = sd; if (DIAG) acc[nlay * NA + 3] = sd; }
+        }
+        const int ctop = sh.misc[d.nwaves + 2];        // the column's highest cloudy layer, -1: none (prepare_column)
+        const int k2 = d.has_aero ? nlay - 1 : ctop;   // layers above k2 are purely absorbing in every lane
+        FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);      // optics of layer k+1
+        FT tau_pc = FT(0), ssa_pc = FT(0), g_pc = FT(0);   // ... without the cloud increment (DIAG)
+        bool cld_p = false;
+        FT lev_top = FT(0), dec_p = FT(0);                 // lev_source[k+2], B(t_lev[k+1]) * pfrac[k+1]
+        auto adding = [&](Stream &t, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff, bool also_twin) {
+            const FT den = m_rcp(FT(1) - t.beta * Rdif);
+            sw.put3(kl, voff, Tdif * den /* A */, (Rdif * t.delta + src_up) * den /* B */, t.beta);
+            const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
+            t.delta = src_dn + Tdif * den * (t.delta + t.beta * src_up);
+            t.beta = beta_n;
+            const FT sdel = seg_sum<BAND>(t.delta * amask);
+            if (writer) { acc[kl * NA + aoff + 1] = sdel; if (DIAG && also_twin) acc[kl * NA + 3] = sdel; }
+        };
+        auto add_layer = [&](int kl, FT lev_bot) {   // layer kl between levels kl and kl+1
+            FT Rdif, Tdif, src_up, src_dn;
+            const FT top = lev_top;   // level source at the top of this layer; its bottom is the next layer's top
+            lev_top = lev_bot;
+            lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_bot, top, Rdif, Tdif, src_up, src_dn);
+            if (kl > k2) {   // beta = 0, R = 0 (wave-uniform: a property of the column)
+                sw.put(kl, 0, Tdif); sw.put(kl, 1, src_up);
+                S.delta = src_dn + Tdif * S.delta;
+                const FT sdel = seg_sum<BAND>(S.delta * amask);
+                if (writer) { acc[kl * NA + 1] = sdel; if (DIAG) acc[kl * NA + 3] = sdel; }
+                if (DIAG) C = S;
+                return;
+            }
+            const bool twin_same = DIAG && kl > ctop;
+            adding(S, Rdif, Tdif, src_up, src_dn, kl, 0, 0, twin_same);
+            if (DIAG) {
+                if (twin_same) C = S;
+                else {
+                    // same coefficients unless this lane's McICA sample put a cloud in the layer
+                    if (cld_p) lw_2stream_coeffs(tau_pc, ssa_pc, g_pc, lev_bot, top, Rdif, Tdif, src_up, src_dn);
+                    adding(C, Rdif, Tdif, src_up, src_dn, kl, 3, 2, false);
+                }
+            }
+        };
+        for (int c = nchunk - 1; c >= 0; c--) {
+            const int k0 = c * CHK, kn = min(CHK, nlay - k0);
+            mw.refill(k0 + kn - 1);
+            __syncthreads();
+            prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
+            __syncthreads();
+            for (int kk = kn - 1; kk >= 0; kk--) {
+                const int k = k0 + kk;
+                FT tau, ssa, gg, pfrac;
+                FT tau_c = FT(0), ssa_c = FT(0), g_c = FT(0);
+                bool cld_k = false;
+                if (DIAG) {
+                    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
+                    tau_c = tau; ssa_c = ssa;
+                    cld_k = d.has_cld && mw.next(k);
+                    lw_layer_increments<FT, true>(d, sh, lb, k, kk, cld_k, tau, ssa, gg);
+                    if (cld_k) lw_layer_increments<FT, true>(d, sh, lb, k, kk, false, tau_c, ssa_c, g_c);
+                    else { tau_c = tau; ssa_c = ssa; g_c = gg; }
+                } else {
                     lw_layer_optics<FT, true>(a, d, sh, lb, k, kk, d.has_cld && mw.next(k), tau, ssa, gg, pfrac);
-                    const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
-                    const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
-                    FT lev_src_k;
-                    if (k == 0) {
-                        const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
-                        sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
-                        src = Num<FT>::pi() * emis * sfc_source;
-                        lev_src_k = lev_src_dec;
-                    } else {
-                        lev_src_k = m_sqrt_pos(inc_prev * lev_src_dec);  // compute_optical_props.jl:189
-                        add_layer(k - 1, lev_src_k);
-                    }
-                    lev_src_bot = lev_src_k;
-                    inc_prev = lev_src_inc;
-                    tau_p = tau; ssa_p = ssa; g_p = gg;
+                }
+                const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
+                const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
+                if (k == nlay - 1) lev_top = lev_src_inc;                    // lev_source[nlev] = lev_src_inc of the last layer
+                else add_layer(k + 1, m_sqrt_pos(lev_src_inc * dec_p));      // compute_optical_props.jl:189
+                dec_p = lev_src_dec;
+                tau_p = tau; ssa_p = ssa; g_p = gg;
+                if (DIAG) { tau_pc = tau_c; ssa_pc = ssa_c; g_pc = g_c; cld_p = cld_k; }
+                if (k == 0) {
+                    const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+                    sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
                 }
             }
-            add_layer(nlay - 1, inc_prev);  // lev_source[nlev] = lev_src_inc of the last layer
-            // ---- top-down fluxes (longwave_2stream.jl:304-333) ----
-            FT F = inc;
-            {
-                const FT su = seg_sum<BAND>((F * albedo + src) * amask), sd = seg_sum<BAND>(F * amask);
-                if (writer) { acc[nlay * NA] = su; acc[nlay * NA + 1] = sd; }
+        }
+        add_layer(0, dec_p);  // lev_source[1] = lev_src_dec of the first layer
+        // ---- surface: U_1 = (1 - emis) D_1 + pi emis B_sfc,  D_1 = beta_1 U_1 + delta_1 ----
+        const FT alb = FT(1) - emis, src_sfc = Num<FT>::pi() * emis * sfc_source;
+        FT U = m_div(src_sfc + alb * S.delta, FT(1) - alb * S.beta);
+        FT Uc = DIAG ? m_div(src_sfc + alb * C.delta, FT(1) - alb * C.beta) : FT(0);
+        {
+            const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(S.beta * U * amask);
+            if (writer) { acc[0] = su; acc[1] += sb; }
+            if (DIAG) {
+                const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(C.beta * Uc * amask);
+                if (writer) { acc[2] = suc; acc[3] += sbc; }
             }
-            for (int kh = nlay - 1; kh >= 0; kh -= DB) {
-                // DB levels per batch: all scratch loads are issued before the dependent FMA chain
-                FT A[DB], B[DB], AL[DB];
+        }
+        // ---- sweep 2, bottom-up.  Rows of three values up to layer k2 (DIAG: up to ctop with the twin's own rows behind them,
+        //      above that the all-sky rows serve both), rows of two values above k2.  DBT levels per batch: all scratch
+        //      loads are issued before the dependent FMA chain ----
+        constexpr int DBT = DIAG ? DB / 2 : DB;  // the twin doubles the batch registers
+        for (int phase = (DIAG ? 0 : 1); phase < 2; phase++) {
+            const int k_lo = DIAG && phase == 1 ? ctop + 1 : 0, k_end = DIAG && phase == 0 ? ctop + 1 : k2 + 1;
+            const bool own = phase == 0;
+            for (int kl = k_lo; kl < k_end; kl += DBT) {
+                FT A[DBT], B[DBT], BE[DBT], Ac[DIAG ? DBT : 1], Bc[DIAG ? DBT : 1], BEc[DIAG ? DBT : 1];
 #pragma unroll
-                for (int j = 0; j < DB; j++) {
-                    const int k = kh - j >= 0 ? kh - j : 0;
-                    sw.get3(k, 0, A[j], B[j], AL[j]);
+                for (int j = 0; j < DBT; j++) {
+                    const int k = kl + j < k_end ? kl + j : k_end - 1;
+                    sw.get3(k, 0, A[j], B[j], BE[j]);
+                    if (DIAG) {
+                        if (own) sw.get3(k, 3, Ac[j], Bc[j], BEc[j]);
+                        else { Ac[j] = A[j]; Bc[j] = B[j]; BEc[j] = BE[j]; }
+                    }
                 }
-                if (!BAND && DB == 16) {
-                    // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
-                    FT pu[16], pd[16];
+                if (!BAND && !DIAG && DBT == 16) {
+                    FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        const bool in = kh - j >= 0;
-                        if (in) F = A[j] * F + B[j];
-                        pu[j] = in ? F * AL[j] * amask : FT(0);
-                        pd[j] = in ? F * amask : FT(0);
+                        const bool in = kl + j < k_end;
+                        if (in) U = A[j] * U + B[j];
+                        pu[j] = in ? U * amask : FT(0);
+                        pb[j] = in ? BE[j] * U * amask : FT(0);
                     }
-                    FT wu[4], wd[4];
+                    FT wu[4], wb[4];
                     wave_sum16(pu, wu);
-                    wave_sum16(pd, wd);
+                    wave_sum16(pb, wb);
                     if ((lane & 15) == 15) {  // row r holds batch entries j = i + 4 r
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            const int k = kh - (i + 4 * (lane >> 4));
-                            if (k >= 0) { acc[k * NA] += wu[i]; acc[k * NA + 1] = wd[i]; }
+                            const int j = i + 4 * (lane >> 4), lev = kl + j + 1;
+                            if (kl + j < k_end) { acc[lev * NA] = wu[i]; acc[lev * NA + 1] += wb[i]; }
+                        }
+                    }
+                } else if (!BAND && DIAG && DBT == 8) {
+                    FT pa[16], pc[16];  // two streams x (U, beta U) x 8 levels: one 16-value reduction per stream
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const bool in = kl + j < k_end;
+                        if (in) { U = A[j] * U + B[j]; Uc = Ac[j] * Uc + Bc[j]; }
+                        pa[j] = in ? U * amask : FT(0);
+                        pa[j + 8] = in ? BE[j] * U * amask : FT(0);
+                        pc[j] = in ? Uc * amask : FT(0);
+                        pc[j + 8] = in ? BEc[j] * Uc * amask : FT(0);
+                    }
+                    FT wa[4], wc[4];
+                    wave_sum16(pa, wa);
+                    wave_sum16(pc, wc);
+                    if ((lane & 15) == 15) {  // rows 0, 1: U sums of entries j = i + 4 r; rows 2, 3: beta U sums
+                        const int r = lane >> 4;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int j = i + 4 * (r & 1), lev = kl + j + 1;
+                            if (kl + j < k_end) {
+                                if (r < 2) { acc[lev * NA] = wa[i]; acc[lev * NA + 2] = wc[i]; }
+                                else { acc[lev * NA + 1] += wa[i]; acc[lev * NA + 3] += wc[i]; }
+                            }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < DB; j++) {
-                        if (kh - j >= 0) {
-                            const int k = kh - j;
-                            F = A[j] * F + B[j];
-                            const FT su = seg_sum<BAND>(F * AL[j] * amask), sd = seg_sum<BAND>(F * amask);
-                            if (writer) { acc[k * NA] += su; acc[k * NA + 1] = sd; }
-                        }
-                    }
-                }
-            }
-        } else {
-            // ---- DIAG, sweep 1, TOP-DOWN: the same layer relations (longwave_2stream.jl:273-333)
-            //     U_{k+1} = T U_k + R D_{k+1} + S_up ,   D_k = T D_{k+1} + R U_k + S_dn
-            // closed from the top instead of from the surface, as sw_solve_kernel does: D_k = beta_k U_k + delta_k with
-            // beta = 0, delta = inc_flux at the top of the domain,
-            //     den = 1 / (1 - beta_{k+1} R),  beta_k = R + T^2 beta_{k+1} den,
-            //     delta_k = S_dn + T den (delta_{k+1} + beta_{k+1} S_up)
-            // (the mirror image of Eqs 9-11; same fluxes).  Closed this way, everything ABOVE the column's highest cloudy
-            // layer is the same for the clear-sky twin and the all-sky stream - same optics, same sources, the same boundary
-            // above - so up there the twin has no arithmetic of its own and no scratch rows (the second sweep reads the
-            // all-sky rows for both).  Closed from the surface the two streams differ from the LOWEST cloudy layer up, which is
-            // nearly the whole column.  Per level the sweep keeps A = T den, B = (R delta + S_up) den and beta_{k+1}; delta
-            // only enters D additively, so its g-point sum is taken on the fly.  The optics run one layer ahead of the adding
-            // step, whose lower level source sqrt(inc[k-1] dec[k]) needs the Planck fraction of the layer below. ----
-            struct Stream { FT beta, delta; };
-            Stream S{FT(0), inc}, C{FT(0), inc};
-            MaskWalk<false> mw(m0, m1, nlay, sh.mask);
-            {
-                const FT sd = seg_sum<BAND>(inc * amask);
-                if (writer) { acc[nlay * NA + 1] = sd; acc[nlay * NA + 3] = sd; }
-            }
-            const int twin_upto = sh.misc[d.nwaves + 2];   // last layer with own clear-sky rows (the highest cloudy layer), -1: none
-            FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);      // optics of layer k+1
-            FT tau_pc = FT(0), ssa_pc = FT(0), g_pc = FT(0);   // ... without the cloud increment
-            bool cld_p = false;
-            FT lev_top = FT(0), dec_p = FT(0);                 // lev_source[k+2], B(t_lev[k+1]) * pfrac[k+1]
-            auto adding = [&](Stream &t, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff, bool also_twin) {
-                const FT den = m_rcp(FT(1) - t.beta * Rdif);
-                sw.put3(kl, voff, Tdif * den /* A */, (Rdif * t.delta + src_up) * den /* B */, t.beta);
-                const FT beta_n = Rdif + Tdif * Tdif * t.beta * den;
-                t.delta = src_dn + Tdif * den * (t.delta + t.beta * src_up);
-                t.beta = beta_n;
-                const FT sdel = seg_sum<BAND>(t.delta * amask);
-                if (writer) { acc[kl * NA + aoff + 1] = sdel; if (also_twin) acc[kl * NA + 3] = sdel; }
-            };
-            auto add_layer = [&](int kl, FT lev_bot) {   // layer kl between levels kl and kl+1
-                FT Rdif, Tdif, src_up, src_dn;
-                lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_bot, lev_top, Rdif, Tdif, src_up, src_dn);
-                const bool twin_same = kl > twin_upto;
-                adding(S, Rdif, Tdif, src_up, src_dn, kl, 0, 0, twin_same);
-                if (twin_same) C = S;
-                else {
-                    // same coefficients unless this lane's McICA sample put a cloud in the layer
-                    if (cld_p) lw_2stream_coeffs(tau_pc, ssa_pc, g_pc, lev_bot, lev_top, Rdif, Tdif, src_up, src_dn);
-                    adding(C, Rdif, Tdif, src_up, src_dn, kl, 3, 2, false);
-                }
-                lev_top = lev_bot;
-            };
-            for (int c = nchunk - 1; c >= 0; c--) {
-                const int k0 = c * CHK, kn = min(CHK, nlay - k0);
-                mw.refill(k0 + kn - 1);
-                __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
-                __syncthreads();
-                for (int kk = kn - 1; kk >= 0; kk--) {
-                    const int k = k0 + kk;
-                    FT tau, ssa, gg, pfrac;
-                    gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
-                    FT tau_c = tau, ssa_c = ssa, g_c = FT(0);
-                    const bool cld_k = d.has_cld && mw.next(k);
-                    lw_layer_increments<FT, true>(d, sh, lb, k, kk, cld_k, tau, ssa, gg);
-                    if (cld_k) lw_layer_increments<FT, true>(d, sh, lb, k, kk, false, tau_c, ssa_c, g_c);
-                    else { tau_c = tau; ssa_c = ssa; g_c = gg; }
-                    const FT lev_src_dec = sh.ch->Blev[kk * NBMAX + lb.ibnd] * pfrac;
-                    const FT lev_src_inc = sh.ch->Blev[(kk + 1) * NBMAX + lb.ibnd] * pfrac;
-                    if (k == nlay - 1) lev_top = lev_src_inc;                    // lev_source[nlev] = lev_src_inc of the last layer
-                    else add_layer(k + 1, m_sqrt_pos(lev_src_inc * dec_p));      // compute_optical_props.jl:189
-                    dec_p = lev_src_dec;
-                    tau_p = tau; ssa_p = ssa; g_p = gg;
-                    tau_pc = tau_c; ssa_pc = ssa_c; g_pc = g_c; cld_p = cld_k;
-                    if (k == 0) {
-                        const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
-                        sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
-                    }
-                }
-            }
-            add_layer(0, dec_p);  // lev_source[1] = lev_src_dec of the first layer
-            // ---- surface: U_1 = (1 - emis) D_1 + pi emis B_sfc,  D_1 = beta_1 U_1 + delta_1 ----
-            const FT alb = FT(1) - emis, src_sfc = Num<FT>::pi() * emis * sfc_source;
-            FT U = m_div(src_sfc + alb * S.delta, FT(1) - alb * S.beta);
-            FT Uc = m_div(src_sfc + alb * C.delta, FT(1) - alb * C.beta);
-            {
-                const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(S.beta * U * amask);
-                const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(C.beta * Uc * amask);
-                if (writer) { acc[0] = su; acc[1] += sb; acc[2] = suc; acc[3] += sbc; }
-            }
-            // ---- sweep 2, bottom-up: U_{k+1} = A U_k + B,  D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1}.  Layers [0, twin_upto]
-            //      carry their own clear-sky rows, the layers above them share the all-sky rows ----
-            constexpr int DBT = DB / 2;  // the twin doubles the batch registers
-            for (int phase = 0; phase < 2; phase++) {
-                const int k_lo = phase == 1 ? twin_upto + 1 : 0, k_end = phase == 0 ? twin_upto + 1 : nlay;
-                const bool own = phase == 0;
-                for (int kl = k_lo; kl < k_end; kl += DBT) {
-                    FT A[DBT], B[DBT], BE[DBT], Ac[DBT], Bc[DBT], BEc[DBT];
-#pragma unroll
                     for (int j = 0; j < DBT; j++) {
-                        const int k = kl + j < k_end ? kl + j : k_end - 1;
-                        sw.get3(k, 0, A[j], B[j], BE[j]);
-                        if (own) sw.get3(k, 3, Ac[j], Bc[j], BEc[j]);
-                        else { Ac[j] = A[j]; Bc[j] = B[j]; BEc[j] = BE[j]; }
-                    }
-                    if (!BAND && DBT == 8) {
-                        FT pa[16], pc[16];  // two streams x (U, beta U) x 8 levels: one 16-value reduction per stream
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const bool in = kl + j < k_end;
-                            if (in) { U = A[j] * U + B[j]; Uc = Ac[j] * Uc + Bc[j]; }
-                            pa[j] = in ? U * amask : FT(0);
-                            pa[j + 8] = in ? BE[j] * U * amask : FT(0);
-                            pc[j] = in ? Uc * amask : FT(0);
-                            pc[j + 8] = in ? BEc[j] * Uc * amask : FT(0);
-                        }
-                        FT wa[4], wc[4];
-                        wave_sum16(pa, wa);
-                        wave_sum16(pc, wc);
-                        if ((lane & 15) == 15) {  // rows 0, 1: U sums of entries j = i + 4 r; rows 2, 3: beta U sums
-                            const int r = lane >> 4;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const int j = i + 4 * (r & 1), lev = kl + j + 1;
-                                if (kl + j < k_end) {
-                                    if (r < 2) { acc[lev * NA] = wa[i]; acc[lev * NA + 2] = wc[i]; }
-                                    else { acc[lev * NA + 1] += wa[i]; acc[lev * NA + 3] += wc[i]; }
-                                }
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < DBT; j++) {
-                            if (kl + j < k_end) {
-                                const int lev = kl + j + 1;
-                                U = A[j] * U + B[j];
+                        if (kl + j < k_end) {
+                            const int lev = kl + j + 1;
+                            U = A[j] * U + B[j];
+                            const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
+                            if (writer) { acc[lev * NA] = su; acc[lev * NA + 1] += sb; }
+                            if (DIAG) {
                                 Uc = Ac[j] * Uc + Bc[j];
-                                const FT su = seg_sum<BAND>(U * amask), sb = seg_sum<BAND>(BE[j] * U * amask);
                                 const FT suc = seg_sum<BAND>(Uc * amask), sbc = seg_sum<BAND>(BEc[j] * Uc * amask);
-                                if (writer) { acc[lev * NA] = su; acc[lev * NA + 1] += sb; acc[lev * NA + 2] = suc; acc[lev * NA + 3] += sbc; }
+                                if (writer) { acc[lev * NA + 2] = suc; acc[lev * NA + 3] += sbc; }
                             }
+                        }
+                    }
+                }
+            }
+        }
+        // rows of two values: U_{k+1} = T U_k + S_up; D_{k+1} = delta_{k+1} is already in the accumulators
+        for (int kl = k2 + 1; kl < nlay; kl += DB) {
+            FT A[DB], B[DB];
+#pragma unroll
+            for (int j = 0; j < DB; j++) {
+                const int k = kl + j < nlay ? kl + j : nlay - 1;
+                A[j] = sw.get(k, 0); B[j] = sw.get(k, 1);
+            }
+            if (!BAND) {
+                FT pu[16], pc[16];   // 16 g-point sums per stream in one 16-value reduction
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const bool in = kl + j < nlay;
+                    if (in) { U = A[j] * U + B[j]; if (DIAG) Uc = A[j] * Uc + B[j]; }
+                    pu[j] = in ? U * amask : FT(0);
+                    pc[j] = DIAG && in ? Uc * amask : FT(0);
+                }
+                FT wu[4], wc[4];
+                wave_sum16(pu, wu);
+                if constexpr (DIAG) wave_sum16(pc, wc);
+                if ((lane & 15) == 15) {  // row r holds batch entries j = i + 4 r
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int j = i + 4 * (lane >> 4), lev = kl + j + 1;
+                        if (kl + j < nlay) {
+                            acc[lev * NA] = wu[i];
+                            if constexpr (DIAG) acc[lev * NA + 2] = wc[i];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < DB; j++) {
+                    if (kl + j < nlay) {
+                        const int lev = kl + j + 1;
+                        U = A[j] * U + B[j];
+                        const FT su = seg_sum<BAND>(U * amask);
+                        if (writer) acc[lev * NA] = su;
+                        if (DIAG) {
+                            Uc = A[j] * Uc + B[j];
+                            const FT suc = seg_sum<BAND>(Uc * amask);
+                            if (writer) acc[lev * NA + 2] = suc;
                         }
                     }
                 }
