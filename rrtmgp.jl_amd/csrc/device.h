@@ -401,7 +401,8 @@ struct ColShared {
     int mscale_row;      // = max_int
     FT *mscale;          // [CH][max_int] minor-gas scalings of the current chunk, slot-contiguous per layer (pairs of slots)
     FT *acc;             // [nseg][nlev][n_acc]
-    int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish
+    int *misc;           // [0..nwaves): cloudy g-points per wave; [nwaves]: pl_sfc_loc; [+1]: cld start; [+2]: cld finish; [+3]: next column;
+                         // [+4]: highest layer with a scattering particle, cloud or aerosol (-1: none)
     FT *miscf;           // [0]: pl_sfc_f
     uint64_t *mask;      // McICA masks of columns with more than 128 layers and clouds: [word][256 lanes], else unused
     // TabCache: the small lookup tables the preparation steps index with data-dependent positions, copied once per
@@ -433,7 +434,7 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base
     s.mscale_row = d.max_int;
     s.mscale = carve<FT>(p, (size_t)(d.max_int > 0 ? d.max_int : MINOR_PAIR) * CHK);
     s.acc = carve<FT>(p, (size_t)d.nseg * d.nlev * d.n_acc);
-    s.misc = carve<int>(p, d.nwaves + 4);
+    s.misc = carve<int>(p, d.nwaves + 5);
     s.miscf = carve<FT>(p, 4);
     s.mask = carve<uint64_t>(p, d.has_cld && d.nlay > 128 ? (size_t)((d.nlay + 63) / 64 + 1) * 256 : 0);
     s.tab_t_ref = carve<FT>(p, d.n_t_ref);
@@ -623,15 +624,19 @@ __device__ inline void prepare_column(const ColShared<FT, CHK> &sh, const ColDim
         for (int w = 0; w < d.nwaves; w++) sh.misc[w] = 0;
         sh.misc[d.nwaves + 1] = nlay;  // first cloudy layer (min over layers below)
         sh.misc[d.nwaves + 2] = -1;    // last cloudy layer (max)
+        sh.misc[d.nwaves + 4] = -1;    // last layer with a cloud or an aerosol: everything above it only absorbs (longwave)
     }
     __syncthreads();
-    if (d.has_cld) {
+    if (d.has_cld || d.has_aero) {
         // _get_start / _get_finish, cloud_optics.jl:310-322 (0-based, -1 when clear), one layer per thread
-        for (int k = tid; k < nlay; k += nt)
-            if (sh.lay[k].cld_frac > FT(0)) {
+        for (int k = tid; k < nlay; k += nt) {
+            const bool cl = d.has_cld && sh.lay[k].cld_frac > FT(0);
+            if (cl) {
                 atomicMin(&sh.misc[d.nwaves + 1], k);
                 atomicMax(&sh.misc[d.nwaves + 2], k);
             }
+            if (cl || sh.lay[k].aero_mask) atomicMax(&sh.misc[d.nwaves + 4], k);
+        }
         __syncthreads();
         if (tid == 0 && sh.misc[d.nwaves + 1] == nlay) sh.misc[d.nwaves + 1] = -1;
     }

@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
         // What the closure from the top buys is everything ABOVE the column's highest cloudy layer (k > k2):
         //   * gas-only longwave layers do not scatter (ssa = 0: R = 0 exactly), so beta stays 0 up there: D = delta is
         //     complete after this sweep, den = 1, and the second sweep needs only A = T and B = S_up - TWO stored values
-        //     and one g-point sum per level instead of three and two (LW 15.0 -> 13.7 ms; aerosols scatter, so with them
-        //     k2 is the top layer and nothing changes);
+        //     and one g-point sum per level instead of three and two (LW 15.1 -> 13.9 ms; aerosols scatter too: k2 is the
+        //     highest layer with a cloud or an aerosol);
         //   * DIAG: above the highest cloudy layer the clear-sky twin IS the all-sky stream - same optics, same sources,
         //     the same boundary above: no coefficients, no adding step, no scratch rows of its own (the second sweep reads
         //     the all-sky rows for both).  Closed from the surface the two differ from the LOWEST cloudy layer up.
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             if (writer) { acc[nlay * NA + 1] = sd; if (DIAG) acc[nlay * NA + 3] = sd; }
         }
         const int ctop = sh.misc[d.nwaves + 2];        // the column's highest cloudy layer, -1: none (prepare_column)
-        const int k2 = d.has_aero ? nlay - 1 : ctop;   // layers above k2 are purely absorbing in every lane
+        const int k2 = sh.misc[d.nwaves + 4];          // highest layer with a cloud or an aerosol: the layers above it only absorb
         FT tau_p = FT(0), ssa_p = FT(0), g_p = FT(0);      // optics of layer k+1
         FT tau_pc = FT(0), ssa_pc = FT(0), g_pc = FT(0);   // ... without the cloud increment (DIAG)
         bool cld_p = false;
