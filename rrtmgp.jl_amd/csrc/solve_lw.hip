@@ -6,11 +6,13 @@
 //
 // One workgroup per column, one lane per g-point, layers in chunks of CH whose
 // band-level records are prepared cooperatively in LDS (device.h).  Two-stream: a
-// single bottom-up sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
-// reflectance/transmittance and the adding step, and leaves 3 numbers per level
-// (A, B, albedo; the src term is summed over g-points on the fly) so that the
-// top-down sweep is two FMAs per level:
-//     F_k = A_k F_{k+1} + B_k ,   U_k = albedo_k F_k + src_k .
+// single TOP-DOWN sweep fuses gas/cloud/aerosol optics, Planck sources, the layer
+// reflectance/transmittance and the adding step closed from the top of the domain
+// (D_k = beta_k U_k + delta_k; the mirror image of the reference's Eqs 9-11), and leaves
+// 3 numbers per level (A, B, beta; delta is summed over g-points on the fly) - 2 above the
+// column's highest cloud / aerosol layer, where nothing scatters and beta stays 0 - so that the
+// bottom-up sweep is two FMAs per level:
+//     U_{k+1} = A_k U_k + B_k ,   D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1} .
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
 #include "device.h"
 
