@@ -1,7 +1,8 @@
 // device.h — device-side building blocks shared by the LW and SW column kernels.
 //
 // Execution model (gfx950): one workgroup per column, one lane per g-point
-// (wavefront w of the group owns g-points 64w..64w+63, i.e. a few whole bands).
+// (a wavefront owns 64 g-points = a few whole bands; with whole 16-g-point bands build_gas deals the bands to the
+// wavefronts by minor-gas slot count, DevGas::lane_gpt; otherwise wavefront w owns g-points 64w..64w+63).
 //
 //  * prepare_column (lane = layer): everything that depends on the layer only —
 //    gas table of volume mixing ratios, T / ln p interpolation indices and
@@ -1010,7 +1011,7 @@ __device__ __forceinline__ GasLoads<FT, SW> gas_issue(const DevGas<FT> &lk, cons
         G.p000 = a.y; G.p100 = b.y; G.p010 = c.y; G.p110 = d.y; G.r000 = e.y; G.r100 = f.y; G.r010 = g.y; G.r110 = h.y;
     }
     // (compute_tau_rayleigh, gas_optics.jl:430-444: the four (eta, T) corners of krayl arrive in slot 0 of the first
-    // contributor group below, and (h2o + 1) col_dry as that slot's scaling)
+    // slot pair below, and (h2o + 1) col_dry as that slot's scaling)
     // compute_tau_minor, gas_optics.jl:344-412 (scalings hoisted to prepare_chunk).
     // The slots of a g-point sit in pairs, and a kminor entry holds a pair at eta and eta + 1 (build_gas): one 16-byte
     // gather per T plane and one 8-byte LDS read of the 2 scalings serve two contributors.  The first pair is loaded

@@ -19,25 +19,31 @@
 
 namespace rrtmgp {
 
+// lw_2stream_coeffs (src/rte/longwave_2stream.jl:149-222) of a purely absorbing layer (gas only: every layer above the
+// column's highest cloud / aerosol layer, 3 of 4 cells of an all-sky column).  The general expressions with ssa = 0
+// substituted: gamma1 = D, gamma2 = 0, k = D, RT_term = 1/(2D), hence Rdif = 0, Tdif = e^{-D tau}, emis_fac = 1 - Tdif and
+// dBz = dB (1 - Tdif) / (D tau).  No sqrt, one reciprocal instead of three.
+template <typename FT>
+__device__ __forceinline__ void lw_absorbing_coeffs(FT tau, FT lev_src_bot, FT lev_src_top, FT &Tdif, FT &src_up, FT &src_dn) {
+    const FT lw_diff_sec = FT(1.66);
+    FT e1, om1;
+    exp_pair(tau * lw_diff_sec, e1, om1);
+    Tdif = e1;
+    const FT dB = lev_src_bot - lev_src_top;
+    const FT dBz = m_div(dB * om1, lw_diff_sec * tau);
+    const bool pos = tau > FT(0);
+    src_up = pos ? Num<FT>::pi() * (lev_src_top * om1 - e1 * dB + dBz) : FT(0);
+    src_dn = pos ? Num<FT>::pi() * (lev_src_bot * om1 + e1 * dB - dBz) : FT(0);
+}
+
 // lw_2stream_coeffs, src/rte/longwave_2stream.jl:149-222
 template <typename FT>
 __device__ __forceinline__ void lw_2stream_coeffs(FT tau, FT ssa, FT g, FT lev_src_bot, FT lev_src_top, FT &Rdif,
                                                   FT &Tdif, FT &src_up, FT &src_dn) {
     const FT lw_diff_sec = FT(1.66);
-    if (__all(ssa == FT(0))) {
-        // Every lane of the wavefront is a purely absorbing layer (gas only: 3 of 4 cells of an all-sky
-        // column).  The expressions below are the general ones with ssa = 0 substituted: gamma1 = D,
-        // gamma2 = 0, k = D, RT_term = 1/(2D), hence Rdif = 0, Tdif = e^{-D tau}, emis_fac = 1 - Tdif and
-        // dBz = dB (1 - Tdif) / (D tau).  No sqrt, one reciprocal instead of three.
-        FT e1, om1;
-        exp_pair(tau * lw_diff_sec, e1, om1);
+    if (__all(ssa == FT(0))) {   // every lane of the wavefront is a purely absorbing layer
         Rdif = FT(0);
-        Tdif = e1;
-        const FT dB = lev_src_bot - lev_src_top;
-        const FT dBz = m_div(dB * om1, lw_diff_sec * tau);
-        const bool pos = tau > FT(0);
-        src_up = pos ? Num<FT>::pi() * (lev_src_top * om1 - e1 * dB + dBz) : FT(0);
-        src_dn = pos ? Num<FT>::pi() * (lev_src_bot * om1 + e1 * dB - dBz) : FT(0);
+        lw_absorbing_coeffs(tau, lev_src_bot, lev_src_top, Tdif, src_up, src_dn);
         return;
     }
     const FT gamma1 = lw_diff_sec * (FT(1) - FT(0.5) * ssa * (FT(1) + g));
@@ -210,8 +216,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
             FT Rdif, Tdif, src_up, src_dn;
             const FT top = lev_top;   // level source at the top of this layer; its bottom is the next layer's top
             lev_top = lev_bot;
-            lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_bot, top, Rdif, Tdif, src_up, src_dn);
-            if (kl > k2) {   // beta = 0, R = 0 (wave-uniform: a property of the column)
+            if (kl > k2) {   // gas only in every lane: R = 0, beta stays 0 (wave-uniform: a property of the column)
+                lw_absorbing_coeffs(tau_p, lev_bot, top, Tdif, src_up, src_dn);
                 sw.put(kl, 0, Tdif); sw.put(kl, 1, src_up);
                 S.delta = src_dn + Tdif * S.delta;
                 const FT sdel = seg_sum<BAND>(S.delta * amask);
@@ -219,6 +225,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WA
                 if (DIAG) C = S;
                 return;
             }
+            lw_2stream_coeffs(tau_p, ssa_p, g_p, lev_bot, top, Rdif, Tdif, src_up, src_dn);
             const bool twin_same = DIAG && kl > ctop;
             adding(S, Rdif, Tdif, src_up, src_dn, kl, 0, 0, twin_same);
             if (DIAG) {
