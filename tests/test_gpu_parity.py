@@ -159,6 +159,58 @@ def test_minor_gas_slot_pairs_and_bands_dealt_to_wavefronts(monkeypatch):
     assert maxdiff(outs["dealt"][1], outs["identity"][1], SWN) < 1e-10
 
 
+@pytest.mark.parametrize("FT,tol", [(np.float64, 1e-8), (np.float32, 1e-3)])
+def test_lw_two_value_rows_above_the_highest_scattering_layer(tables64, FT, tol):
+    """The LW two-stream kernels close the adding from the top and keep two values per level above the column's highest
+    layer with a cloud or an aerosol (csrc/solve_lw.hip).  Columns that put that boundary everywhere: no particle at all
+    (the whole column in two-value rows), a cloud in the TOP layer (none), a lone aerosol layer above the clouds, a lone
+    cloud layer at the surface; with and without the clear-sky twin, against the oracle's bottom-up adding."""
+    from rrtmgp_jl_amd.states import Flux
+    t = {k: v.astype(FT) for k, v in tables64.items()}
+    nlay = 40
+
+    def columns(ft):
+        as_, lb, _ = S.make_columns(8, nlay, ft, seed=23, clouds=True, aerosols=True, cld_frac=1.0)
+        cs, ae = as_.cloud_state, as_.aerosol_state
+        cloudy = np.asarray(cs.cld_frac) > 0
+        assert cloudy.any(axis=0).sum() >= 4
+        k_hi = int(np.max(np.nonzero(cloudy.any(axis=1))[0]))
+        assert k_hi < nlay - 4
+        cld_src = np.argwhere(np.asarray(cs.cld_path_liq) > 0)[0]
+        cld_val = {n: getattr(cs, n)[cld_src[0], cld_src[1]] for n in ("cld_r_eff_liq", "cld_r_eff_ice", "cld_path_liq", "cld_path_ice", "cld_frac")}
+        aer_src = np.argwhere(np.asarray(ae.aero_mass) > 0)[0]
+        aer_val = (ae.aero_mass[tuple(aer_src)], ae.aero_size[tuple(aer_src)])
+
+        def put_cloud(k, c):   # a liquid cloud like the ones make_columns builds
+            for n, v in cld_val.items():
+                getattr(cs, n)[k, c] = v
+
+        def clear_column(c, aerosols_too=True):
+            for n in cld_val:
+                getattr(cs, n)[:, c] = 0
+            if aerosols_too:
+                ae.aero_mass[:, :, c] = 0
+
+        clear_column(0)                                   # nothing scatters: k2 = -1
+        clear_column(1); put_cloud(nlay - 1, 1)           # cloud in the top layer: no two-value rows
+        clear_column(2); put_cloud(0, 2)                  # lone cloud at the surface
+        clear_column(3, aerosols_too=False)               # aerosols only (make_columns puts them below 700 hPa)
+        ae.aero_mass[aer_src[0], k_hi + 3, 4], ae.aero_size[aer_src[0], k_hi + 3, 4] = aer_val   # a lone aerosol layer above the clouds
+        return as_, lb
+
+    (as64, lb64), (as_, lb) = columns(np.float64), columns(FT)
+    ref_clr = Flux.allocate(8, nlay + 1, np.float64)
+    ref = O.solve_lw(as64, lb64, tables64["lw"], tables64["cld_lw"], tables64["aero_lw"], seed=3, clear_flux=ref_clr)
+    out = hip_lw(as_, lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=3)
+    assert maxdiff(out, ref, LWN) < tol
+    clr = Flux.allocate(8, nlay + 1, FT)
+    out = hip_lw(as_, lb, t["lw"], t["cld_lw"], t["aero_lw"], seed=3, clear_flux=clr)
+    assert maxdiff(out, ref, LWN) < tol and maxdiff(clr, ref_clr, LWN) < tol
+    # without the aerosol lookup the boundary is the highest cloudy layer
+    ref = O.solve_lw(as64, lb64, tables64["lw"], tables64["cld_lw"], seed=3)
+    assert maxdiff(hip_lw(as_, lb, t["lw"], t["cld_lw"], seed=3), ref, LWN) < tol
+
+
 @pytest.mark.parametrize("nlay", [129, 150, 200])
 def test_deep_columns_with_clouds(tables64, nlay):
     """More than 128 layers with clouds: the McICA mask no longer fits two 64-bit registers per g-point; its words live
