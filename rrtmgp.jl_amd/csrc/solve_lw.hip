@@ -15,6 +15,7 @@
 //     U_{k+1} = A_k U_k + B_k ,   D_{k+1} = beta_{k+1} U_{k+1} + delta_{k+1} .
 // Broadband fluxes are wavefront sums over g-points (fixed DPP order).
 #include "device.h"
+#include <climits>
 
 
 namespace rrtmgp {
@@ -124,9 +125,10 @@ constexpr int DB = 16;  // levels per batch of the top-down sweeps
 // CA: -1 = clouds / aerosols are run-time flags; 0..3 = (clouds | aerosols << 1) known at compile time (the main
 // two-stream instance: absent optics leave no code, no kernel arguments in registers and no lane masks behind).
 // HALF: the main (no-aerosol) instances once more with 8-layer chunks, for columns whose 16-layer records would push a
-// workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.
+// workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.  Float32 DIAG
+// instances: once more with 8-layer chunks AND at 128 VGPRs (4 waves per SIMD), taken when that admits one more workgroup.
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? RR_DIAG_MIN_WAVES : RR_MIN_WAVES) : HALF ? RR_F64_HALF_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR_DIAG_MIN_WAVES) : RR_MIN_WAVES) : HALF ? RR_F64_HALF_WAVES : 2)) lw_solve_kernel(const LwArgs<FT> a) {
     static_assert(TWOSTREAM, "the no-scattering solver is lw_noscat_kernel");
     extern __shared__ __align__(16) char smem[];
     constexpr int CHK = HALF ? half_chunk_layers<FT>() : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
@@ -707,7 +709,31 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
                 : half ? (cld ? lw_solve_kernel<FT, true, false, false, 1, true> : lw_solve_kernel<FT, true, false, false, 0, true>)
                 : cld  ? lw_solve_kernel<FT, true, false, false, 1>
                 : aero ? lw_solve_kernel<FT, true, false, false, 2> : lw_solve_kernel<FT, true, false, false, 0>;
-    const int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
+    int grid = column_grid(ws, as.ncol, threads, lds, (const void *)kern);
+    if constexpr (sizeof(FT) == 4) {
+        // One-pass diagnostic, Float32: the same instances exist once more at 128 VGPRs (4 waves per SIMD instead of 3) with
+        // 8-layer chunks (HALF).  They spill (51 / 32 registers, LW / SW) and pay off when they put one more workgroup on a CU
+        // than the 168-VGPR instances AND the sweep scratch of that workgroup still finds room behind the L2: measured
+        // (tools/experiments/diag4_sweep.sh, profiles/r04_diag4_sweep_ab.txt; both flux sets, M columns/s)
+        //   40 layers 4.89 -> 5.39 (4 vs 3 per CU), 64 layers 3.20 -> 3.26, with aerosols 2.76 -> 3.00, 128 layers 1.16 -> 1.29 (3 vs 2),
+        //   but 72 layers 2.81 -> 2.74 and 96 layers 2.00 -> 1.96 (4 vs 3 per CU, 450 -> 600 MB of scratch).
+        // So: when they admit one more workgroup, up to 64 layers or when the others would leave a CU with two.
+        static const bool no_diag_half = getenv("RRTMGP_HIP_NO_DIAG_HALF") != nullptr;  // A/B switch
+        if (diag && !no_diag_half && grid > 0) {
+            auto k4 = aero ? lw_solve_kernel<FT, true, false, true, 3, true> : lw_solve_kernel<FT, true, false, true, 1, true>;
+            const size_t lds4 = carve_shared(dummy_half, (char *)nullptr, d);
+            const int cap3 = column_grid(ws, INT_MAX, threads, lds, (const void *)kern);
+            const int cap4 = lds4 <= 160 * 1024 ? column_grid(ws, INT_MAX, threads, lds4, (const void *)k4) : -1;
+            if (cap4 > cap3 && as.ncol > cap3 && (d.nlay <= 64 || cap3 <= 2 * ws->n_cu)) {
+                kern = k4; lds = lds4; grid = std::min(as.ncol, cap4);
+            }
+        } else if (diag && !no_diag_half) {   // the 16-layer records do not fit the LDS at all: the 8-layer ones may
+            auto k4 = aero ? lw_solve_kernel<FT, true, false, true, 3, true> : lw_solve_kernel<FT, true, false, true, 1, true>;
+            const size_t lds4 = carve_shared(dummy_half, (char *)nullptr, d);
+            const int g4 = lds4 <= 160 * 1024 ? column_grid(ws, as.ncol, threads, lds4, (const void *)k4) : -1;
+            if (g4 > 0) { kern = k4; lds = lds4; grid = g4; }
+        }
+    }
     if (grid < 0) return grid;
     const size_t sweep_bytes = (size_t)grid * d.nlev * (!twostream ? (a.n_angles == 1 ? 2 : 3) : diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
     int rc = scratch_ensure(ws, sweep_bytes + 256);
