@@ -80,6 +80,43 @@ def test_hip_one_pass_matches_oracle_and_two_solves(tables64, FT, tol_lw, tol_sw
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("aerosols", [False, True])
+def test_float32_instances_of_four_waves_per_simd(tables64, aerosols, monkeypatch, capfd):
+    """Float32 launches with more columns than the 168-VGPR instances keep resident take the 128-VGPR / 8-layer-chunk
+    instances of the one-pass diagnostic (csrc/solve_lw.hip, solve_sw.hip: launch_*).  The other tests of this file are too
+    small to reach them: 1 100 columns against the Float32 oracle, budgets of the reference's Float32 ratchet."""
+    from rrtmgp_jl_amd import rte
+    FT, ncol, nlay = np.float32, 1100, 20
+    t = {k: v.astype(FT) for k, v in tables64.items()}
+    as_, lb, sb = S.make_columns(ncol, nlay, FT, seed=77, aerosols=aerosols, night_fraction=0.2, random_cld_frac=True)
+    monkeypatch.setenv("RRTMGP_HIP_TRACE_LAUNCH", "1")
+    for sw in (False, True):
+        sfx = "sw" if sw else "lw"
+        lk, cld, aero = t[sfx], t["cld_" + sfx], t["aero_" + sfx] if aerosols else None
+        names, tol = (NAMES_SW, 1.2e-1) if sw else (NAMES_LW, 1e-3)
+        ref_clear = Flux.allocate(ncol, nlay + 1, FT, sw=sw)
+        ref = (oracle.solve_sw if sw else oracle.solve_lw)(as_, sb if sw else lb, lk, cld, aero, seed=8, clear_flux=ref_clear)
+        cls, solve, bcs = (rte.TwoStreamSWRTE, rte.solve_sw, sb) if sw else (rte.TwoStreamLWRTE, rte.solve_lw, lb)
+        one = cls(ncol, nlay, FT, bcs)
+        clear = Flux.allocate(ncol, nlay + 1, FT, sw=sw)
+        capfd.readouterr()
+        solve(one, as_, lk, cld, aero, seed=8, clear_flux=clear)
+        trace = capfd.readouterr().err
+        assert "-> 4 workgroups per CU" in trace and "-> 3 workgroups per CU" in trace, trace   # both asked, the larger taken
+        for n in names:
+            assert np.abs(np.float64(getattr(one.flux, n)) - np.float64(getattr(ref, n))).max() <= tol, (sfx, "all-sky", n)
+            assert np.abs(np.float64(getattr(clear, n)) - np.float64(getattr(ref_clear, n))).max() <= tol, (sfx, "clear", n)
+        # the first 700 columns alone are few enough for the 168-VGPR instances: the same arithmetic per (layer, g-point)
+        from rrtmgp_jl_amd.sharding import shard_container
+        as_p, bcs_p = shard_container(as_, 0, 700, ncol), shard_container(bcs, 0, 700, ncol)
+        part, pclear = cls(700, nlay, FT, bcs_p), Flux.allocate(700, nlay + 1, FT, sw=sw)
+        solve(part, as_p, lk, cld, aero, seed=8, clear_flux=pclear)
+        for n in names:
+            np.testing.assert_array_equal(getattr(part.flux, n), getattr(one.flux, n)[:, :700])
+            np.testing.assert_array_equal(getattr(pclear, n), getattr(clear, n)[:, :700])
+
+
+@pytest.mark.gpu
 def test_hip_one_pass_argument_errors(tables64):
     from rrtmgp_jl_amd import rte, _lib
     t = tables64
