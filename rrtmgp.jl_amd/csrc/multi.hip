@@ -133,8 +133,10 @@ int multi_run(rrtmgp_workspace *ws, const std::function<int(rrtmgp_workspace *, 
         for (size_t s = 1; s < n; s++) workers.emplace_back(run, s);
         run(0);
         for (auto &t : workers) t.join();
+    } else if (n == 1) {
+        run(0);  // HIPDevice(0) / Workspace(device=[0]): one shard, nothing to fan out — no pool, the caller's thread
     } else {
-        if (!ws->workers && n > 1) ws->workers = new ShardWorkers(ws->shards);
+        if (!ws->workers) ws->workers = new ShardWorkers(ws->shards);
         std::vector<std::function<void()>> jobs(n);
         for (size_t s = 0; s < n; s++) {
             jobs[s] = [&run, s] { run(s); };

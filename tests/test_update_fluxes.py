@@ -196,7 +196,7 @@ def test_fused_step_where_the_one_pass_diagnostic_does_not_apply(tables64, what)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("device", [[0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("device", [[0], [0, 0], [0, 0, 0]])   # [0]: what HIPDevice(0) creates (one shard, no worker pool)
 def test_fused_step_on_a_sharded_workspace(tables64, device):
     one, _ = _pair(tables64, np.float64, "diag", True, ncol=13)
     many, _ = _pair(tables64, np.float64, "diag", True, ncol=13, device=device, interpolation=GA.NoInterpolation)
