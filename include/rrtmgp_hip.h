@@ -563,6 +563,23 @@ int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, 
  * rrtmgp_hip_mcica_uniform(...) in [0, 1).  Host-callable so tests can pin it. */
 double rrtmgp_hip_mcica_uniform(uint64_t seed, int64_t gcol, int64_t igpt, int32_t is_sw, int32_t draw);
 
+/* ---- device math forms ---------------------------------------------------- */
+
+/* The per-g-point loops do not call libm or the compiler's `/`: they use the forms of rrtmgp.jl_amd/csrc/device.h (v_exp_f32 /
+ * v_rcp_f32 / v_rsq_f32 based).  This entry evaluates one of them element-wise on HOST arrays of `n` values of `ftype` (`y`
+ * only for the quotients, else NULL) so that a test can state their accuracy against a wider type: the reference computes
+ * with Julia's exp (< 1 ulp) and IEEE `/` and sqrt (docs/src/precision.md).  Measured maxima: tests/test_primitives.py. */
+enum {
+    RRTMGP_PRIM_EXP_NEG = 0,      /* e^-x, x >= 0: transmissivities, the direct beam */
+    RRTMGP_PRIM_EXP_PAIR_E1 = 1,  /* e^-x of the two-stream pair (longwave_2stream.jl:167, shortwave_2stream.jl:204) */
+    RRTMGP_PRIM_EXP_PAIR_OM1 = 2, /* 1 - e^-x = -expm1(-x) of the same pair */
+    RRTMGP_PRIM_RCP = 3,          /* 1 / x */
+    RRTMGP_PRIM_DIV = 4,          /* x / y */
+    RRTMGP_PRIM_SQRT_POS = 5,     /* sqrt(x), x positive and normal */
+    RRTMGP_PRIM_IEEE_DIV = 6      /* x / y of increment_2stream (optics_utils.jl:189-223): correctly rounded in every build */
+};
+int rrtmgp_hip_eval_primitive(int device, int32_t op, int32_t ftype, const void *x, const void *y, void *out, int64_t n);
+
 /* ---- diagnostics ---------------------------------------------------------- */
 
 /* Copies the calling thread's last error message (NUL-terminated) into buf. */

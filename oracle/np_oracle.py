@@ -1,12 +1,16 @@
 """TEST INFRASTRUCTURE: an independent numpy restatement of the hot path, used only to
 cross-check the C oracle (oracle/rrtmgp_oracle.c) — two transcriptions of the reference
-that share no code.  Vectorised over g-points, explicit loops over columns and layers;
-Float64; clouds with a deterministic mask (cld_frac in {0, 1}), no aerosols.
+that share no code.  Vectorised over g-points, explicit loops over columns and layers; Float64.
+Written from the Julia sources, never from the C oracle.
 
 Follows (reference file:line): gas optics src/optics/gas_optics.jl:87-444 and
 optics_utils.jl:34-223; LW sources compute_optical_props.jl:129-198; cloud optics
 cloud_optics.jl:70-244; two-stream solvers src/rte/longwave_2stream.jl:149-334 and
 shortwave_2stream.jl:189-392; no-scattering LW longwave_noscat.jl:171-301.
+Round 5: McICA max-random overlap with fractional cloud fractions (cloud_optics.jl:264-334) on this back end's
+counter-based stream (include/rrtmgp_hip.h, "McICA stream"); MERRA aerosol optics (aerosol_optics.jl:1-451) with the
+550 nm AOD diagnostic; no-scattering SW (shortwave_noscat.jl:60-148); gray optics and the four gray solvers
+(gray_optics_kernels.jl:12-251); column amounts and relative humidity (gas_optics.jl:16-80, column_amounts.jl:20-70).
 """
 import numpy as np
 
@@ -106,9 +110,62 @@ def gas_optics_column(lk, as_, c):
     return tau, ssa, pfrac
 
 
-def cloud_increment(tau, ssa, g, lkc, as_, c, bnd, delta):
-    cs = as_.cloud_state
-    nlay = tau.shape[0]
+# ---- McICA (round 5) --------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """splitmix64 finaliser — the mixing function of the stream spec in include/rrtmgp_hip.h."""
+    z &= _M64
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & _M64
+    return z ^ (z >> 31)
+
+
+def mcica_uniform(seed, gcol, igpt, is_sw, draw):
+    """Draw number `draw` (0-based) of g-point `igpt` (1-based) of global column `gcol` (1-based): the Float64 in [0, 1)
+    that stands in for Random.rand() of cloud_optics.jl:279,291."""
+    G = 0x9e3779b97f4a7c15
+    k = _mix64(seed + G * gcol)
+    k = _mix64(k ^ (igpt | ((1 if is_sw else 0) << 32)))
+    k = _mix64(k + G * (draw + 1))
+    return (k >> 11) * (1.0 / 9007199254740992.0)
+
+
+def cloud_mask_column(cld_frac, seed, gcol, ngpt, is_sw):
+    """build_cloud_mask!(…, MaxRandomOverlap), cloud_optics.jl:264-334, for every g-point of one column -> bool (nlay, ngpt).
+    `cld_frac` is in its working precision: the comparisons are Float64 draw against FT(1) - cld_frac, as in Julia."""
+    nlay = len(cld_frac)
+    ft = cld_frac.dtype.type
+    mask = np.zeros((nlay, ngpt), bool)
+    cloudy = np.nonzero(cld_frac > 0)[0]
+    if len(cloudy) == 0:
+        return mask
+    start, finish = cloudy[0], cloudy[-1]          # _get_start / _get_finish (0-based here)
+    for g in range(ngpt):
+        draw = 0
+        cf_above = cld_frac[finish]
+        r_above = mcica_uniform(seed, gcol, g + 1, is_sw, draw); draw += 1
+        m_above = r_above >= float(ft(1) - cf_above)
+        mask[finish, g] = m_above
+        for k in range(finish - 1, start - 1, -1):
+            cf = cld_frac[k]
+            if cf > 0:
+                if m_above:
+                    r = r_above
+                else:
+                    r = mcica_uniform(seed, gcol, g + 1, is_sw, draw) * float(ft(1) - cf_above); draw += 1
+                m = r >= float(ft(1) - cf)
+                r_above = r
+            else:
+                m = False
+            mask[k, g] = m
+            cf_above, m_above = cf, m
+    return mask
+
+
+def _cloud_props(lkc, cs, k, c, b):
+    """compute_lookup_cld_liq_props / _ice_props, cloud_optics.jl:154-244 -> (tl, tl*ssa, tl*ssa*g, ti, ti*ssa, ti*ssa*g)"""
     nl, ni = int(lkc.dims[2]), int(lkc.dims[3])
     lo_l, up_l, lo_i, up_i = lkc.bounds
 
@@ -124,27 +181,164 @@ def cloud_increment(tau, ssa, g, lkc, as_, c, bnd, delta):
         a = (1 - fac) * tab[2 * n + loc - 1] + fac * tab[2 * n + loc]
         t = max(ext * path, 0.0)
         return t, s * t, a * s * t
+    return (props(lkc.liqdata[:, b], nl, lo_l, up_l, cs.cld_r_eff_liq[k, c], cs.cld_path_liq[k, c]) +
+            props(lkc.icedata[:, b, cs.ice_rgh - 1], ni, lo_i, up_i, cs.cld_r_eff_ice[k, c], cs.cld_path_ice[k, c]))
+
+
+def _increment(tau, ssa, g, sel, t2, s2, g2):
+    """increment_2stream, optics_utils.jl:189-223, on the g-points `sel` of one layer (arrays modified in place)."""
+    t1, s1, g1 = tau[sel], ssa[sel], g[sel]
+    tt = t1 + t2
+    ss = t1 * s1 + t2 * s2
+    g[sel] = (t1 * s1 * g1 + t2 * s2 * g2) / np.maximum(EPS, ss)
+    ssa[sel] = ss / np.maximum(EPS, tt)
+    tau[sel] = tt
+
+
+def _delta_scale(t, s, g):
+    """delta_scale, optics_utils.jl:202-223 (f = g^2 in the non-cancelling forms)"""
+    w = s * (1 - g) * (1 + g)
+    om = (1 - s) + w
+    return om * t, w / max(EPS, om), g / max(EPS, 1 + g)
+
+
+def cloud_increment(tau, ssa, g, lkc, as_, c, bnd, delta, mask=None, onescalar=False):
+    """add_cloud_optics_2stream! / _1scalar!, cloud_optics.jl:1-130.  `mask` (nlay, ngpt) bool: the McICA sample; None:
+    every g-point of a layer with cld_frac > 0 (what cld_frac = 1 samples)."""
+    cs = as_.cloud_state
+    nlay = tau.shape[0]
     for k in range(nlay):
         if not cs.cld_frac[k, c] > 0:
             continue
         for b in range(lkc.liqdata.shape[1]):
             gs = np.nonzero(bnd == b)[0]
-            tl, tls, tlsg = props(lkc.liqdata[:, b], nl, lo_l, up_l, cs.cld_r_eff_liq[k, c], cs.cld_path_liq[k, c])
-            ti, tis, tisg = props(lkc.icedata[:, b, cs.ice_rgh - 1], ni, lo_i, up_i, cs.cld_r_eff_ice[k, c],
-                                  cs.cld_path_ice[k, c])
+            if mask is not None:
+                gs = gs[mask[k, gs]]
+            if len(gs) == 0:
+                continue
+            tl, tls, tlsg, ti, tis, tisg = _cloud_props(lkc, cs, k, c, b)
+            if onescalar:
+                tau[k, gs] += (tl - tls) + (ti - tis)
+                continue
             t2, s2 = tl + ti, tls + tis
             g2 = (tlsg + tisg) / max(EPS, s2)
             s2 = s2 / max(EPS, t2)
             if delta:
-                w = s2 * (1 - g2) * (1 + g2)
-                om = (1 - s2) + w
-                t2, s2, g2 = om * t2, w / max(EPS, om), g2 / max(EPS, 1 + g2)
-            t1, s1, g1 = tau[k, gs], ssa[k, gs], g[k, gs]
-            tt = t1 + t2
-            ss = t1 * s1 + t2 * s2
-            g[k, gs] = (t1 * s1 * g1 + t2 * s2 * g2) / np.maximum(EPS, ss)
-            ssa[k, gs] = ss / np.maximum(EPS, tt)
-            tau[k, gs] = tt
+                t2, s2, g2 = _delta_scale(t2, s2, g2)
+            _increment(tau[k], ssa[k], g[k], gs, t2, s2, g2)
+
+
+# ---- MERRA aerosols (round 5): aerosol_optics.jl:141-451 -----------------------------------------------------
+def _loc_factor(xi, x):
+    """interp1d_loc_factor + loc_lower for non-uniform grids, optics_utils.jl:21-27,51-62 -> (0-based loc, factor)"""
+    n = len(x)
+    if xi < x[0]:
+        return 0, 0.0
+    if xi > x[-1]:
+        return n - 2, 1.0
+    if xi <= x[0]:
+        loc = 0
+    else:
+        loc = n - 2
+        for i in range(n):
+            if xi < x[i]:
+                loc = i - 1
+                break
+    return loc, (xi - x[loc]) / (x[loc + 1] - x[loc])
+
+
+def _merra_bin(limits, size):
+    """locate_merra_size_bin, aerosol_optics.jl:438-451: the first bin that holds the size, else the LAST bin (0-based)."""
+    nb = limits.shape[1]
+    b = 0
+    for i in range(nb):
+        if limits[0, i] <= size <= limits[1, i]:
+            return i
+        b = nb - 1
+    return b
+
+
+def aerosol_layer(lka, b, mass, size, rh):
+    """compute_lookup_aerosol, aerosol_optics.jl:141-233: (tau, tau*ssa, tau*ssa*g) summed over the 15 MERRA species of
+    one layer in band b (0-based).  `mass`, `size`: the (15,) slices of the layer."""
+    tc = tsc = tsgc = 0.0
+    loc, f = _loc_factor(rh, lka.rh_levels)
+
+    def add(t, w, a):
+        nonlocal tc, tsc, tsgc
+        ts = t * w
+        tc += t; tsc += ts; tsgc += ts * a
+
+    def rh_tab(tab):   # (3, nrh): interpolated in relative humidity
+        return [tab[i, loc] * (1 - f) + tab[i, loc + 1] * f for i in range(3)]
+    for ia in (1, 8, 9, 10, 11):          # dust (1-based species, as in the reference)
+        m = mass[ia - 1]
+        if m > 0:
+            d = lka.dust[:, _merra_bin(lka.size_bin_limits, size[ia - 1]), b]
+            add(m * d[0], d[1], d[2])
+    for ia in (2, 12, 13, 14, 15):        # sea salt
+        m = mass[ia - 1]
+        if m > 0:
+            e, w, a = rh_tab(lka.sea_salt[:, :, _merra_bin(lka.size_bin_limits, size[ia - 1]), b])
+            add(m * e, w, a)
+    if mass[2] > 0:                       # 3: sulfate
+        e, w, a = rh_tab(lka.sulfate[:, :, b]); add(mass[2] * e, w, a)
+    if mass[3] > 0:                       # 4: hydrophilic black carbon
+        e, w, a = rh_tab(lka.black_carbon_rh[:, :, b]); add(mass[3] * e, w, a)
+    if mass[4] > 0:                       # 5: hydrophobic black carbon
+        d = lka.black_carbon[:, b]; add(mass[4] * d[0], d[1], d[2])
+    if mass[5] > 0:                       # 6: hydrophilic organic carbon
+        e, w, a = rh_tab(lka.organic_carbon_rh[:, :, b]); add(mass[5] * e, w, a)
+    if mass[6] > 0:                       # 7: hydrophobic organic carbon
+        d = lka.organic_carbon[:, b]; add(mass[6] * d[0], d[1], d[2])
+    return tc, tsc, tsgc
+
+
+def aerosol_increment(tau, ssa, g, lka, as_, c, bnd, delta, onescalar=False, collect_aod=False):
+    """add_aerosol_optics_2stream! / _1scalar!, aerosol_optics.jl:17-131.  Returns (aod_ext, aod_sca) of the 550 nm band
+    (sums over the masked layers in layer order, reset per g-point call as :99-100 does — so the band's value) or None."""
+    ae = as_.aerosol_state
+    nlay = tau.shape[0]
+    aod = None
+    for b in range(lka.dust.shape[2]):
+        gs = np.nonzero(bnd == b)[0]
+        want = collect_aod and (b + 1 == lka.iband_550nm)
+        ext = sca = 0.0
+        for k in range(nlay):
+            mass = ae.aero_mass[:, k, c]
+            if not (mass > 0).any():      # compute_aero_mask!, aerosol_optics.jl:464-483
+                continue
+            t, ts, tsg = aerosol_layer(lka, b, mass, ae.aero_size[:, k, c], as_.layerdata[3, k, c])
+            if want:
+                ext += t; sca += ts
+            if onescalar:
+                tau[k, gs] += t - ts
+                continue
+            ga = tsg / max(EPS, ts)
+            sa = ts / max(EPS, t)
+            if delta:
+                t, sa, ga = _delta_scale(t, sa, ga)
+            _increment(tau[k], ssa[k], g[k], gs, t, sa, ga)
+        if want:
+            aod = (ext, sca)
+    return aod
+
+
+def optics_column(lk, as_, c, lkc, lka, twostream, seed=0, col_offset=0):
+    """compute_optical_props! of one column (compute_optical_props.jl:27-388): gas, then clouds under the McICA sample,
+    then aerosols.  Returns tau, ssa, g, pfrac (nlay, ngpt), the number of g-points with a cloudy layer, and the AOD pair."""
+    bnd = lk.major_gpt2bnd - 1
+    sw = bool(lk.is_sw)
+    tau, ssa, pf = gas_optics_column(lk, as_, c)
+    g = np.zeros_like(tau)
+    ncloudy, aod = 0, None
+    if lkc is not None:
+        mask = cloud_mask_column(np.asarray(as_.cloud_state.cld_frac)[:, c], seed, col_offset + c + 1, tau.shape[1], sw)
+        ncloudy = int(mask.any(axis=0).sum())
+        cloud_increment(tau, ssa, g, lkc, as_, c, bnd, delta=sw, mask=mask, onescalar=not twostream)
+    if lka is not None:
+        aod = aerosol_increment(tau, ssa, g, lka, as_, c, bnd, delta=sw, onescalar=not twostream, collect_aod=sw)
+    return tau, ssa, g, pf, ncloudy, aod
 
 
 def lw_sources(lk, as_, c, pfrac):
@@ -187,7 +381,7 @@ def lw_coeffs(tau, ssa, g, bot, top):
     return R, T, su, sd
 
 
-def solve_lw_2stream(lk, as_, bcs, lkc=None, per_gpoint=False):
+def solve_lw_2stream(lk, as_, bcs, lkc=None, per_gpoint=False, lka=None, seed=0, col_offset=0):
     """`per_gpoint=True` returns (nlev, ncol, n_gpt) arrays instead of the g-point sums."""
     nlay, ncol = as_.layerdata.shape[1:]
     bnd = lk.major_gpt2bnd - 1
@@ -195,10 +389,7 @@ def solve_lw_2stream(lk, as_, bcs, lkc=None, per_gpoint=False):
     red = (lambda x: x) if per_gpoint else (lambda x: x.sum())
     up = np.zeros(shape); dn = np.zeros(shape)
     for c in range(ncol):
-        tau, ssa, pf = gas_optics_column(lk, as_, c)
-        g = np.zeros_like(tau)
-        if lkc is not None:
-            cloud_increment(tau, ssa, g, lkc, as_, c, bnd, False)
+        tau, ssa, g, pf, _, _ = optics_column(lk, as_, c, lkc, lka, True, seed, col_offset)
         _, lev, sfc = lw_sources(lk, as_, c, pf)
         emis = bcs.sfc_emis[bnd, c]
         alb = [1 - emis]
@@ -218,17 +409,13 @@ def solve_lw_2stream(lk, as_, bcs, lkc=None, per_gpoint=False):
     return up, dn
 
 
-def solve_lw_noscat(lk, as_, bcs, lkc=None, Ds=1.0 / 0.6096748751, w=1.0):
+def solve_lw_noscat(lk, as_, bcs, lkc=None, Ds=1.0 / 0.6096748751, w=1.0, lka=None, seed=0, col_offset=0):
     nlay, ncol = as_.layerdata.shape[1:]
     bnd = lk.major_gpt2bnd - 1
     up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol))
     thr = np.sqrt(np.sqrt(EPS))
     for c in range(ncol):
-        tau, ssa, pf = gas_optics_column(lk, as_, c)
-        if lkc is not None:
-            g = np.zeros_like(tau); s2 = np.zeros_like(tau); t2 = np.zeros_like(tau)
-            cloud_increment(t2, s2, g, lkc, as_, c, bnd, False)   # combined cloud tau, ssa on a zero background
-            tau = tau + (t2 - t2 * s2)                              # absorption only, cloud_optics.jl:45
+        tau, _, _, pf, _, _ = optics_column(lk, as_, c, lkc, lka, False, seed, col_offset)   # absorption only, cloud_optics.jl:45
         lay, lev, sfc = lw_sources(lk, as_, c, pf)
         emis = bcs.sfc_emis[bnd, c]
 
@@ -281,18 +468,25 @@ def sw_coeffs(tau, ssa, g, mu0):
     return Rdir * sc, Tdir * sc, Rdif, Tdif
 
 
-def solve_sw_2stream(lk, as_, bcs, lkc=None):
+def solve_sw_2stream(lk, as_, bcs, lkc=None, lka=None, seed=0, col_offset=0, diag=None):
+    """`diag`: a dict that receives `cover` (ncol,) — the fraction of g-points whose McICA sample has a cloudy layer — and
+    `aod_ext` / `aod_sca` (ncol,): computed for night columns too, as the reference does (shortwave_2stream.jl:86-131)."""
     nlay, ncol = as_.layerdata.shape[1:]
     bnd = lk.major_gpt2bnd - 1
     up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol)); dr = np.zeros((nlay + 1, ncol))
+    if diag is not None:
+        diag.update(cover=np.zeros(ncol), aod_ext=np.zeros(ncol), aod_sca=np.zeros(ncol))
     for c in range(ncol):
         mu0 = bcs.cos_zenith[c]
+        if not mu0 > 0 and diag is None:
+            continue
+        tau, ssa, g, _, ncloudy, aod = optics_column(lk, as_, c, lkc, lka, True, seed, col_offset)
+        if diag is not None:
+            diag["cover"][c] = ncloudy / tau.shape[1]
+            if aod is not None:
+                diag["aod_ext"][c], diag["aod_sca"][c] = aod
         if not mu0 > 0:
             continue
-        tau, ssa, _ = gas_optics_column(lk, as_, c)
-        g = np.zeros_like(tau)
-        if lkc is not None:
-            cloud_increment(tau, ssa, g, lkc, as_, c, bnd, True)
         top = bcs.toa_flux[c] * lk.solar_src_scaled * mu0
         inv = 1 / max(mu0, EPS)
         dirs = np.zeros((nlay + 1, tau.shape[1]))
@@ -318,3 +512,171 @@ def solve_sw_2stream(lk, as_, bcs, lkc=None):
             F = (T * F + R * src[k] + Tdir * dirs[k + 1]) * den
             up[k, c] = (F * alb[k] + src[k]).sum(); dn[k, c] = (F + dirs[k]).sum(); dr[k, c] = dirs[k].sum()
     return up, dn, dr
+
+
+def solve_sw_noscat(lk, as_, bcs):
+    """rte_sw_noscat_solve! / rte_sw_noscat!, shortwave_noscat.jl:60-148: gas optics only (compute_optical_props.jl:263-296),
+    multiplicative Beer-Lambert from the top, flux_up = 0; night columns are zeroed."""
+    nlay, ncol = as_.layerdata.shape[1:]
+    up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol)); dr = np.zeros((nlay + 1, ncol))
+    for c in range(ncol):
+        mu0 = bcs.cos_zenith[c]
+        if not mu0 > 0:
+            continue
+        tau, _, _ = gas_optics_column(lk, as_, c)
+        d = bcs.toa_flux[c] * lk.solar_src_scaled * mu0
+        dr[nlay, c] = d.sum()
+        for k in range(nlay - 1, -1, -1):
+            d = d * np.exp(-tau[k] / max(mu0, EPS))
+            dr[k, c] = d.sum()
+    dn[:] = dr
+    return up, dn, dr
+
+
+# ---- gray atmosphere (round 5): gray_optics_kernels.jl:12-251 ------------------------------------------------
+def gray_tau(otp, p0, dp, p, lat, sw):
+    """compute_gray_optical_thickness_lw / _sw for both parameterisations (gray_optics_kernels.jl:171-251)."""
+    if otp.kind == 0:      # GrayOpticalThicknessSchneider2004
+        if sw:
+            return 0.0
+        ts_by_tt = (otp.te + otp.dt * (1.0 / 3.0 - np.sin(lat / 180.0 * np.pi) ** 2)) / otp.tt
+        d0 = ts_by_tt * ts_by_tt * ts_by_tt * ts_by_tt - 1.0
+        return abs((otp.alpha * d0 * np.exp(otp.alpha * np.log(p / p0)) / p) * dp)   # pow_fast, Numerics.jl:72
+    if sw:                 # GrayOpticalThicknessOGorman2008
+        return abs(2 * otp.tau_0 * (p / p0) * (dp / p0))
+    sig = p / p0
+    return abs((otp.alpha * dp / p) * (otp.fl * sig + (1 - otp.fl) * 4 * sig ** 4) *
+               (otp.tau_e + (otp.tau_p - otp.tau_e) * np.sin(lat / 180.0 * np.pi) ** 2))
+
+
+def _gray_column(gs, c, sw):
+    nlay = gs.p_lay.shape[0]
+    p0 = gs.p_lev[0, c]
+    return np.array([gray_tau(gs.otp, p0, gs.p_lev[k + 1, c] - gs.p_lev[k, c], gs.p_lay[k, c], gs.lat[c], sw)
+                     for k in range(nlay)])
+
+
+def _gray_sources(gs, c):
+    """lay_source, lev_source, sfc_source of compute_optical_props!(…, ::GrayAtmosphericState, …), :12-122"""
+    nlay = gs.p_lay.shape[0]
+    B = lambda T: gs.stefan * (T * T * T * T) / np.pi   # noqa: E731
+    lev = np.zeros(nlay + 1)
+    inc_prev = 0.0
+    for k in range(nlay):
+        dec, inc = B(gs.t_lev[k, c]), B(gs.t_lev[k + 1, c])
+        lev[k] = dec if k == 0 else np.sqrt(inc_prev * dec)
+        inc_prev = inc
+    lev[nlay] = inc_prev
+    return np.array([B(gs.t_lay[k, c]) for k in range(nlay)]), lev, B(gs.t_sfc[c])
+
+
+def solve_lw_gray(gs, bcs, twostream):
+    """The gray LW solvers: one g-point, band 1 (rte_lw_2stream! / rte_lw_noscat_one_angle! on the gray optics)."""
+    nlay, ncol = gs.p_lay.shape
+    up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol))
+    thr = np.sqrt(np.sqrt(EPS))
+    Ds = 1.0 / 0.6096748751
+    for c in range(ncol):
+        tau = _gray_column(gs, c, False)
+        lay, lev, sfc = _gray_sources(gs, c)
+        emis = bcs.sfc_emis[0, c]
+        inc = bcs.inc_flux[c, 0] if bcs.inc_flux is not None else 0.0
+        if twostream:
+            alb, src = [1 - emis], [np.pi * emis * sfc]
+            z = np.zeros(1)
+            co = [lw_coeffs(np.array([tau[k]]), z, z, np.array([lev[k]]), np.array([lev[k + 1]])) for k in range(nlay)]
+            for k in range(nlay):
+                R, T, su, sd = (x[0] for x in co[k])
+                den = 1 / (1 - R * alb[k])
+                alb.append(R + T * T * alb[k] * den)
+                src.append(su + T * den * (src[k] + alb[k] * sd))
+            F = inc
+            dn[nlay, c] = F; up[nlay, c] = F * alb[nlay] + src[nlay]
+            for k in range(nlay - 1, -1, -1):
+                R, T, su, sd = (x[0] for x in co[k])
+                den = 1 / (1 - R * alb[k])
+                F = (T * F + R * src[k] + sd) * den
+                dn[k, c] = F; up[k, c] = F * alb[k] + src[k]
+        else:
+            def source(levs, lays, tl, tr):
+                fact = (1 - tr) / tl - tr if tl > thr else tl * (0.5 + tl * (-1 / 3 + tl / 8))
+                return (1 - tr) * levs + 2 * fact * (lays - levs)
+            I = inc / np.pi
+            dn[nlay, c] = I * np.pi
+            for k in range(nlay - 1, -1, -1):
+                tl = tau[k] * Ds; tr = np.exp(-tl)
+                I = tr * I + source(lev[k], lay[k], tl, tr)
+                dn[k, c] = I * np.pi
+            I = I * (1 - emis) + emis * sfc
+            up[0, c] = I * np.pi
+            for k in range(1, nlay + 1):
+                tl = tau[k - 1] * Ds; tr = np.exp(-tl)
+                I = tr * I + source(lev[k], lay[k - 1], tl, tr)
+                up[k, c] = I * np.pi
+    return up, dn
+
+
+def solve_sw_gray(gs, bcs, twostream):
+    """The gray SW solvers: one g-point with solar fraction 1, ssa = g = 0."""
+    nlay, ncol = gs.p_lay.shape
+    up = np.zeros((nlay + 1, ncol)); dn = np.zeros((nlay + 1, ncol)); dr = np.zeros((nlay + 1, ncol))
+    for c in range(ncol):
+        mu0 = bcs.cos_zenith[c]
+        if not mu0 > 0:
+            continue
+        tau = _gray_column(gs, c, True)
+        top = bcs.toa_flux[c] * mu0
+        if not twostream:
+            d = top
+            dr[nlay, c] = dn[nlay, c] = d
+            for k in range(nlay - 1, -1, -1):
+                d = d * np.exp(-tau[k] / max(mu0, EPS))
+                dr[k, c] = dn[k, c] = d
+            continue
+        inv = 1 / max(mu0, EPS)
+        dirs = np.zeros(nlay + 1); dirs[nlay] = top
+        cum = 0.0
+        for k in range(nlay - 1, -1, -1):
+            cum += tau[k]
+            dirs[k] = top * np.exp(-cum * inv)
+        alb = [bcs.sfc_alb_diffuse[0, c]]
+        src = [dirs[0] * bcs.sfc_alb_direct[0, c]]
+        co = []
+        z = np.zeros(1)
+        for k in range(nlay):
+            Rdir, Tdir, R, T = (x[0] for x in sw_coeffs(np.array([tau[k]]), z, z, mu0))
+            co.append((Tdir, R, T))
+            den = 1 / (1 - R * alb[k])
+            alb.append(R + T * T * alb[k] * den)
+            src.append(Rdir * dirs[k + 1] + T * den * (src[k] + alb[k] * (Tdir * dirs[k + 1])))
+        F = 0.0
+        up[nlay, c] = F * alb[nlay] + src[nlay]; dn[nlay, c] = F + top; dr[nlay, c] = top
+        for k in range(nlay - 1, -1, -1):
+            Tdir, R, T = co[k]
+            den = 1 / (1 - R * alb[k])
+            F = (T * F + R * src[k] + Tdir * dirs[k + 1]) * den
+            up[k, c] = F * alb[k] + src[k]; dn[k, c] = F + dirs[k]; dr[k, c] = dirs[k]
+    return up, dn, dr
+
+
+# ---- column amounts and relative humidity (round 5): gas_optics.jl:16-80, column_amounts.jl:20-70 -------------
+def compute_col_gas(p_lev, params, vmr_h2o=None, lat=None):
+    nlev, ncol = p_lev.shape
+    out = np.zeros((nlev - 1, ncol))
+    for c in range(ncol):
+        g0 = params.grav - 0.02586 * np.cos(2 * np.pi * lat[c] / 180) if lat is not None else params.grav
+        for k in range(nlev - 1):
+            dp = p_lev[k, c] - p_lev[k + 1, c]
+            h = vmr_h2o[k, c] if vmr_h2o is not None else 0.0
+            m_air = params.molmass_dryair + params.molmass_water * h
+            out[k, c] = dp * params.avogad / (100 * 100 * m_air * g0)
+    return out
+
+
+def compute_relative_humidity(p_lay, t_lay, params, vmr_h2o):
+    mwd = params.molmass_water / params.molmass_dryair
+    mmr = vmr_h2o * mwd
+    q = np.maximum(1e-7, mmr / (1 + mmr))
+    es = np.exp((17.67 * (t_lay - 273.16)) / (t_lay - 29.65))
+    return np.maximum(0.01 * (0.263 * p_lay * q) / es, 0)
+

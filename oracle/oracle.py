@@ -43,18 +43,43 @@ def n_threads() -> int:
         return max(1, os.cpu_count() or 1)
 
 
+def load_library(path):
+    """A build of the oracle at `path` with its entry points typed (tests/test_oracle_mutations.py loads deliberately
+    broken builds through this)."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(n_threads(), 32)))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    L = C.CDLL(path)
+    L.rrtmgp_oracle_mcica_uniform.restype = C.c_double
+    L.rrtmgp_oracle_mcica_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+    L.rrtmgp_oracle_interp1d_equispaced.restype = C.c_double
+    L.rrtmgp_oracle_loc_lower_eq.restype = C.c_int64
+    L.rrtmgp_oracle_loc_lower.restype = C.c_int64
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
-        os.environ.setdefault("OMP_NUM_THREADS", str(min(n_threads(), 32)))
-        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-        _lib = C.CDLL(build())
-        _lib.rrtmgp_oracle_mcica_uniform.restype = C.c_double
-        _lib.rrtmgp_oracle_mcica_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
-        _lib.rrtmgp_oracle_interp1d_equispaced.restype = C.c_double
-        _lib.rrtmgp_oracle_loc_lower_eq.restype = C.c_int64
-        _lib.rrtmgp_oracle_loc_lower.restype = C.c_int64
+        _lib = load_library(build())
     return _lib
+
+
+class using:
+    """`with using(other_build): ...` — every oracle call inside runs on `other_build` (a load_library handle)."""
+
+    def __init__(self, other):
+        self.other = other
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self.saved, _lib = _lib, self.other
+        return self.other
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def _check(rc, what):

@@ -70,6 +70,7 @@ EXPORTS = {
     "rrtmgp_hip_host_registered_count": (C.c_int, []),
     "rrtmgp_hip_allocation_counts": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "rrtmgp_hip_eval_primitive": (C.c_int, [C.c_int, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64]),
     "rrtmgp_hip_last_error": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rrtmgp_hip_version": (C.c_char_p, []),
     "rrtmgp_hip_build_flags": (C.c_char_p, []),
@@ -151,3 +152,28 @@ def require_gpu() -> int:
     if n <= 0:
         raise RRTMGPHipError("no HIP device visible: " + last_error())
     return n
+
+
+PRIMITIVES = {"exp_neg": 0, "exp_pair_e1": 1, "exp_pair_om1": 2, "rcp": 3, "div": 4, "sqrt_pos": 5, "ieee_div": 6}
+
+
+def eval_primitive(name: str, x, y=None, device: int = 0, library=None):
+    """One of the kernels' device math forms (include/rrtmgp_hip.h, rrtmgp_hip_eval_primitive) element-wise on numpy arrays.
+    `library`: a ctypes handle of another build of the library (the IEEE-Float32 one); default: the loaded one."""
+    import numpy as np
+    x = np.ascontiguousarray(x)
+    assert x.dtype in (np.float32, np.float64)
+    out = np.empty_like(x)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=x.dtype)
+        assert y.shape == x.shape
+        yp = y.ctypes.data_as(C.c_void_p)
+    L = library if library is not None else lib()
+    fn = L.rrtmgp_hip_eval_primitive
+    fn.restype, fn.argtypes = EXPORTS["rrtmgp_hip_eval_primitive"]
+    rc = fn(device, PRIMITIVES[name], x.dtype.itemsize, x.ctypes.data_as(C.c_void_p), yp, out.ctypes.data_as(C.c_void_p), x.size)
+    if rc != 0:
+        raise RRTMGPHipError(f"eval_primitive({name}): {_abi.ERRORS.get(rc, rc)}")
+    return out
+

@@ -95,9 +95,27 @@ __device__ __forceinline__ double m_div(double a, double b) {
 }
 #endif
 #ifdef RR_PRECISE_F32
-__device__ __forceinline__ float m_rcp(float x) { return 1.0f / x; }
-__device__ __forceinline__ float m_div(float a, float b) { return a / b; }
-__device__ __forceinline__ float m_sqrt_pos(float x) { return sqrtf(x); }
+// IEEE-accurate Float32 forms of the per-g-point loops, written out (round 5) instead of `/`, sqrtf and libm: the compiler's
+// correctly rounded division is 10 instructions between two s_setreg (denormal mode on and off again), sqrtf likewise, and
+// libm's expf / expm1f are ~15 / ~45.  The operands here are well scaled (optical depths, albedos, two-stream denominators:
+// never denormal, never near overflow), which is all these forms need:
+//  * quotient / reciprocal: v_rcp_f32 (1 ulp) + ONE residual correction with FMAs — the rounded result of q + (a - b q) rc,
+//    where the residual is exact: correctly rounded except for ties closer than 2^-23 ulp (the form `ieee_div` has always used);
+//  * square root: v_rsq_f32 + one Heron step on the exact residual x - s^2, same argument: correctly rounded;
+//  * e^-y: see exp_neg_acc below (<= 1 ulp).
+// tests/test_primitives.py measures all of them on the GPU against Float64 (rrtmgp_hip_eval_primitive).
+__device__ __forceinline__ float m_rcp(float x) {
+    const float rc = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, rc, 1.0f), rc, rc);
+}
+__device__ __forceinline__ float m_div(float a, float b) {
+    const float rc = __builtin_amdgcn_rcpf(b), q = a * rc;
+    return fmaf(fmaf(-b, q, a), rc, q);
+}
+__device__ __forceinline__ float m_sqrt_pos(float x) {   // x in [k_min, O(10)]: positive, normal
+    const float r = __builtin_amdgcn_rsqf(x), s = x * r;
+    return fmaf(fmaf(-s, s, x), 0.5f * r, s);
+}
 #else
 __device__ __forceinline__ float m_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -108,14 +126,12 @@ __device__ __forceinline__ double m_sqrt_pos(double x) { return sqrt(x); }
 // (Float32: v_rcp_f32 + one FMA residual correction: within 0.5 ulp + 2^-40 for normal operands.  `/` and __fdiv_rn are the
 // 2.5-ulp form in a translation unit built with -fno-hip-fp32-correctly-rounded-divide-sqrt.)
 __device__ __forceinline__ float ieee_div(float a, float b) {
-#ifdef RR_PRECISE_F32
-    return a / b;   // (that build's `/` is the correctly rounded one)
-#else
     const float rc = __builtin_amdgcn_rcpf(b), q = a * rc;
     return fmaf(fmaf(-b, q, a), rc, q);
-#endif
 }
-__device__ __forceinline__ double ieee_div(double a, double b) { return m_div(a, b); }   // (Newton + residual correction: <= 1 ulp)
+// Float64: NOT the IEEE quotient — v_rcp_f64 + two Newton steps + one residual correction, <= 1 ulp for normal, well-scaled
+// operands (wrong for denormal or near-overflow divisors, which increment_2stream's max(eps, .) denominators never are)
+__device__ __forceinline__ double ieee_div(double a, double b) { return m_div(a, b); }
 template <typename FT> __device__ __forceinline__ FT m_max(FT a, FT b) { return a > b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_min(FT a, FT b) { return a < b ? a : b; }
 template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT(0) ? -a : a; }
@@ -131,7 +147,7 @@ template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT
 __device__ __forceinline__ double exp_reduce(double x, int &ni) {
     // an overflowed optical depth (+inf, or beyond 2^52 ln 2 where the reduction loses r) must saturate to an opaque layer,
     // (0, 1), as libm does, not turn into NaN: everything from 1500 on gives exactly that (2^-2000 underflows to 0)
-    x = __builtin_fmin(x, 1500.0);
+    x = x > 1500.0 ? 1500.0 : x;   // (compare + select, not fmin: a NaN optical depth stays NaN and surfaces in the fluxes)
     const double n = __builtin_rint(x * 1.4426950408889634074);   // x / ln 2
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);  // ln2_hi (the low 21 bits are zero: n * ln2_hi is exact)
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);         // ln2_lo
@@ -174,13 +190,31 @@ __device__ __forceinline__ double m_exp_neg(double y) {
     return __builtin_ldexp(1.0 - m, -ni);
 #endif
 }
+// e^-y for y >= 0 to <= 1 ulp (Julia's exp(::Float32): < 1 ulp) around v_exp_f32, which is 2^p to 1 ulp for any p — what
+// __expf loses is the ARGUMENT: p = -y log2(e) rounded to Float32 is off by up to half an ulp of p, i.e. |p| 2^-24 ln 2 in the
+// result (10 ulp at y = 20).  Here the product is kept as p_hi + p_lo (one FMA recovers the rounding error of the product, a
+// second adds y times the low word of log2 e) and e^-y = 2^p_hi (1 + p_lo ln 2): 6 instructions.  y beyond 200 saturates to
+// 0 like expf (2^-288 underflows); the clamp is a compare + select so that a NaN optical depth stays NaN.
+__device__ __forceinline__ float exp_neg_acc(float y) {
+    y = y > 200.0f ? 200.0f : y;
+    const float L2E_HI = 1.4426950216293335f, L2E_LO = 1.925963033500011e-08f;   // log2(e) = hi + lo
+    const float p = -y * L2E_HI;
+    float pl = fmaf(-y, L2E_HI, -p);
+    pl = fmaf(-y, L2E_LO, pl);
+    const float e = __builtin_amdgcn_exp2f(p);
+    return fmaf(e, pl * 0.6931471824645996f, e);
+}
+#ifdef RR_PRECISE_F32
+__device__ __forceinline__ float m_exp_neg(float y) { return exp_neg_acc(y); }
+#else
 __device__ __forceinline__ float m_exp_neg(float y) { return m_exp(-y); }
+#endif
 __device__ __forceinline__ void exp_pair(float x, float &e1, float &om1) {
 #ifdef RR_PRECISE_F32
-    e1 = expf(-x);
-    om1 = -expm1f(-x);
+    e1 = exp_neg_acc(x);
 #else
     e1 = __expf(-x);
+#endif
     // x <= 1/2: x * sum_{n=0..7} (-x)^n / (n+1)!  (truncation < 2^-27 relative); above: 1 - e1 with e1 < 0.61
     float p = -1.0f / 40320.0f;
     p = fmaf(p, x, 1.0f / 5040.0f);
@@ -191,7 +225,6 @@ __device__ __forceinline__ void exp_pair(float x, float &e1, float &om1) {
     p = fmaf(p, x, -0.5f);
     p = fmaf(p, x, 1.0f);
     om1 = x > 0.5f ? 1.0f - e1 : x * p;
-#endif
 }
 
 template <typename FT> __device__ __forceinline__ FT k_min() { return m_sqrt(Num<FT>::eps()); }

@@ -27,6 +27,15 @@ CASES = {
     "clear_gm": dict(ncol=6, nlay=20, cols=dict(clouds=False, night_fraction=0.3), aero=False),
     "cloudy_full": dict(ncol=6, nlay=24, cols=dict(vmr_kind="full", night_fraction=0.2, inc_flux_ngpt=24), aero=False),
     "aerosol_mcica": dict(ncol=5, nlay=17, cols=dict(aerosols=True, random_cld_frac=True, cos_zenith=0.7), aero=True),
+    # the other two ice roughness classes of LookUpCld (cloud_optics.jl:207-244, LookUpTables.jl:260-284); round 5
+    "ice_rgh1": dict(ncol=4, nlay=14, cols=dict(random_cld_frac=True, night_fraction=0.25), aero=False, ice_rgh=1),
+    "ice_rgh3": dict(ncol=4, nlay=14, cols=dict(random_cld_frac=True, aerosols=True), aero=True, ice_rgh=3),
+    # every MERRA species in play in most layers, particle sizes inside, between and outside the size bins (the "else the
+    # last bin" rule of locate_merra_size_bin, aerosol_optics.jl:438-451), relative humidities beyond both table ends: the
+    # synthetic recipe of make_columns activates ONE species per (layer, column) and only low down — the mutation check of
+    # round 5 (tests/test_oracle_mutations.py) showed that a wrong species list passed `aerosol_mcica` unnoticed
+    "aerosol_dense": dict(ncol=3, nlay=12, cols=dict(aerosols=True, random_cld_frac=True, night_fraction=0.3), aero=True,
+                          dense_aerosols=True),
 }
 SEED = 2026
 
@@ -41,7 +50,20 @@ def tables():
 
 def inputs(case):
     c = CASES[case]
-    return S.make_columns(c["ncol"], c["nlay"], np.float64, seed=SEED, n_bnd_lw=3, n_bnd_sw=3, **c["cols"])
+    as_, lb, sb = S.make_columns(c["ncol"], c["nlay"], np.float64, seed=SEED, n_bnd_lw=3, n_bnd_sw=3, **c["cols"])
+    if "ice_rgh" in c:
+        as_.cloud_state.ice_rgh = c["ice_rgh"]
+    if c.get("dense_aerosols"):
+        rng = np.random.default_rng(SEED + 1)
+        ae = as_.aerosol_state
+        shape = ae.aero_mass.shape                      # (15, nlay, ncol)
+        on = rng.uniform(size=shape) < 0.6
+        on[:, 0, :] = True                              # a layer with all fifteen
+        on[:, 1, :] = False                             # and one with none (aero_mask false)
+        ae.aero_mass[...] = np.where(on, 10.0 ** rng.uniform(-7.0, -4.0, shape), 0.0)
+        ae.aero_size[...] = rng.choice([0.05, 0.1, 0.5, 1.0, 1.4, 1.8, 2.9, 3.0, 5.0, 6.0, 9.9, 10.0, 12.0, 30.0], shape)
+        as_.layerdata[3] = rng.uniform(-0.1, 1.2, as_.layerdata[3].shape)   # relative humidity, beyond both ends of rh_levels
+    return as_, lb, sb
 
 
 def run(case, solve_lw, solve_sw):
@@ -72,6 +94,6 @@ def run(case, solve_lw, solve_sw):
 if __name__ == "__main__":
     from oracle import oracle as O
     here = os.path.dirname(os.path.abspath(__file__))
-    for case in CASES:
+    for case in (sys.argv[1:] or CASES):   # (name the new cases to leave the committed fixtures of the others untouched)
         np.savez_compressed(os.path.join(here, f"{case}.npz"), **run(case, O.solve_lw, O.solve_sw))
         print("wrote", case)

@@ -85,11 +85,14 @@ def _random_configuration(seed, FT):
     as_, lb, sb = S.make_columns(ncol, nlay, FT, seed=seed, vmr_kind=vmr_kind, clouds=clouds, aerosols=aerosols,
                                  n_bnd_lw=n_bnd, n_bnd_sw=n_bnd, night_fraction=0.3, random_cld_frac=True,
                                  inc_flux_ngpt=lw.n_gpt if rng.integers(0, 2) else 0)
+    ice_rgh = 2
+    if clouds:   # every ice roughness class of LookUpCld (cloud_optics.jl:207-244); its own generator: the draws above stay as they were
+        ice_rgh = as_.cloud_state.ice_rgh = int(np.random.default_rng(5000 + seed).integers(1, 4))
     c_lw, c_sw = (cl, cs) if clouds else (None, None)
     a_lw, a_sw = (al, asw) if aerosols else (None, None)
     metric = np.asfortranarray(rng.uniform(0.9, 1.1, (nlay + 1, ncol)).astype(FT)) if rng.integers(0, 2) else None
     kw = dict(seed=int(rng.integers(0, 2**31)), col_offset=int(rng.integers(0, 10**6)), metric_scaling=metric)
-    tag = f"{np.dtype(FT).name} seed={seed} ncol={ncol} nlay={nlay} bands={gpb_lw}/{gpb_sw} clouds={clouds} aerosols={aerosols} {vmr_kind}"
+    tag = f"{np.dtype(FT).name} seed={seed} ncol={ncol} nlay={nlay} bands={gpb_lw}/{gpb_sw} clouds={clouds} ice_rgh={ice_rgh} aerosols={aerosols} {vmr_kind}"
     failures = []
 
     def check(got, ref, names, what):
