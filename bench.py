@@ -13,11 +13,15 @@ resident in HBM (torch tensors handed to the C ABI as device pointers).
 Prints ONE JSON line on rank 0.  Besides the contract's keys:
   * `step_ms`: min / median / mean of the K timed steps (HIP events on the launch stream, read after the
     timed region; the reference quotes BenchmarkTools' min for its ratchet and the median in its tables);
-  * `roofline`: the dominant kernel's ALGORITHMIC HBM bytes against 8 TB/s as the task contract asks; the path
-    is not HBM-bound (SURVEY.md F8), so the binding FP32-VALU figure is reported next to it as `valu`;
-    `traffic` comes from the committed rocprofv3 PMC summary and carries the git SHA it was taken at
-    (`traffic_source`; `traffic` is null when the summary is missing or was taken on other kernel sources — compared by a
-    hash of csrc/{common.h, device.h, solve_lw.hip, solve_sw.hip, Makefile});
+  * `roofline`: the ceiling that binds — the FP32 vector rate (the path has no contraction and runs HBM at < 1 % of peak,
+    SURVEY.md F8): the DOMINANT kernel's algorithmic flops over its live event time against 157.3 TFLOP/s, per-kernel
+    fractions under `per_kernel`; the HBM view of the task contract (algorithmic bytes against 8 TB/s, PMC traffic and its
+    ratio to the algorithmic bytes) is nested under `hbm`.  `traffic` comes from the committed rocprofv3 PMC summary and
+    carries the git SHA it was taken at (`traffic_source`; null when the summary is missing or was taken on other kernel
+    sources — compared by a hash of csrc/{common.h, device.h, solve_lw.hip, solve_sw.hip, Makefile}); `valu`: both kernels;
+  * `strong_emulated`: BASELINE config 4's shards (4096 / 2048 / 1024 / 512 columns x 72, aerosols) each solved alone on
+    this GPU: the one-GPU prediction of the 1 -> 8 strong-scaling curve;
+  * `rank_devices`: ordinal / name / PCI address of the device every rank ran on;
   * `host_end_to_end`: the same workload handed over as HOST arrays (library stages H2D / D2H over PCIe
     every step): never `value`;
   * `precise_f32`: the IEEE-Float32 build of the library (-DRR_PRECISE_F32, correctly rounded div / sqrt);
@@ -59,6 +63,15 @@ def algorithmic_bytes(nlay, nbnd_lw, nbnd_sw, ft_bytes):
     # one step with the state read once by both solves (1275 elements at nlay = 64)
     step = ((4 + 2 + 5) * nlay + nlev + 1 + nbnd_lw + 2 * nbnd_sw + 2) + (7 * nlev + 4)
     return lw * ft_bytes, sw * ft_bytes, step * ft_bytes
+
+
+def kernel_valu(kernel, kernel_ms, ncol, nlay, n_gpt, peak=VALU_PEAK_TFLOPS, lw_cell=LW_FLOPS_PER_CELL):
+    """A column kernel's algorithmic FP32 rate and its fraction of the vector peak: SURVEY.md section 8(d) flops per
+    (layer, g-point) cell x the cells one launch processes / its duration.  The same function prices the live event time
+    (`roofline.frac`) and the committed profile's average (`roofline.profiled`; tests/test_profiles.py recomputes it)."""
+    cell = lw_cell if kernel.startswith("lw") else SW_FLOPS_PER_CELL
+    tflops = cell * n_gpt * nlay * ncol / (kernel_ms * 1e-3) / 1e12
+    return {"kernel_ms": kernel_ms, "achieved": tflops, "frac": tflops / peak}
 
 
 def parse_args(argv=None):
@@ -346,9 +359,19 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ranks_seen, rank_ms, rank_ncol = 1, [1e3 * elapsed / args.steps], [ncol]
+    # which physical device each rank ran on (ordinal, name, PCI address): lets a scaling record be audited for ranks that
+    # shared a GPU or never showed up
+    pr = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": pr.name,
+          "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+          "uuid": str(getattr(pr, "uuid", "")), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"),
+          "pid": os.getpid()}
+    rank_devices = [me]
     if world > 1:
         cdev = dev if backend == "nccl" else "cpu"
         ranks_seen = dist.get_world_size()
+        rank_devices = [None] * ranks_seen
+        dist.all_gather_object(rank_devices, me)
         mine = torch.tensor([elapsed, float(ncol)], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(ranks_seen)]
         dist.all_gather(every, mine)     # per-rank wall time of the timed region and columns per step
@@ -417,7 +440,12 @@ def main():
         achieved = dom_bytes * ncol / (dom_ms * 1e-3) / 1e9
         flops = flops_col * ncol
         valu_tflops = flops / ((ms_lw + ms_sw) * 1e-3) / 1e12
-        traffic = traffic_source = None
+        lw_flops_col = nlay * lw.n_gpt * lw_cell
+        sw_flops_col = 0.0 if args.lw_only else nlay * sw.n_gpt * SW_FLOPS_PER_CELL
+        lw_tflops = lw_flops_col * ncol / (ms_lw * 1e-3) / 1e12
+        sw_tflops = sw_flops_col * ncol / (ms_sw * 1e-3) / 1e12 if ms_sw > 0 else 0.0
+        dom_flops_col, dom_tflops = (lw_flops_col, lw_tflops) if ms_lw >= ms_sw else (sw_flops_col, sw_tflops)
+        traffic = traffic_source = profiled = None
         prof = os.path.join(ROOT, "profiles", "latest.json")
         default_workload = (not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32"
                             and not args.host and args.clear_sky_diag == "off" and not noscat and clouds and not args.lw_only
@@ -442,6 +470,8 @@ def main():
                 traffic_source = {"profile": pj.get("source"), "git_sha": pj.get("git_sha"),
                                   "profiled_kernel_ms": k.get("avg_us", 0.0) / 1e3}
                 vmem = vmem_pipeline(k)
+                profiled = kernel_valu(dom, k["avg_us"] / 1e3, ncol, nlay, lw.n_gpt if dom.startswith("lw") else sw.n_gpt)
+                profiled["source"] = "rocprofv3 --kernel-trace --stats average of profiles/latest.json (" + str(pj.get("source")) + ")"
         out = {
             "metric": "columns/sec, all-sky LW+SW 2-stream (nlay=64, 256+224 gpt)",
             "value": value,
@@ -467,14 +497,26 @@ def main():
             "step_ms": step_ms,
             # what the process group reported after init_process_group, every rank's own wall time per step (the job's
             # ms_per_step is their MAX) and the columns each rank solved per step
-            "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms, "rank_columns": rank_ncol,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_column": dom_bytes, "kernel_ms": dom_ms,
-                         "note": "path is FP32-VALU/transcendental + table-gather bound, not HBM bound (SURVEY F8)"},
+            "ranks_seen": ranks_seen, "rank_ms_per_step": rank_ms, "rank_columns": rank_ncol, "rank_devices": rank_devices,
+            # The ceiling that binds is the FP32 vector rate (no contraction, HBM at < 1 %): the
+            # contract object prices the DOMINANT kernel's own algorithmic flops against it, with its live event time; the
+            # HBM view the task statement asks for (algorithmic bytes against 8 TB/s, PMC traffic) is nested under `hbm`
+            "roofline": {"bound": "valu", "kernel": dom, "achieved": dom_tflops, "peak": valu_peak, "unit": "TFLOP/s",
+                         "frac": dom_tflops / valu_peak, "kernel_ms": dom_ms, "algorithmic_flops_per_column": dom_flops_col,
+                         "traffic": traffic, "profiled": profiled,
+                         "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_column": dom_bytes, "algorithmic_bytes": dom_bytes * ncol,
+                                 "traffic": traffic, "traffic_ratio": (traffic / (dom_bytes * ncol)) if traffic else None,
+                                 "traffic_source": traffic_source},
+                         "per_kernel": {"lw_solve_kernel": {"ms": ms_lw, "achieved": lw_tflops, "frac": lw_tflops / valu_peak},
+                                        "sw_solve_kernel": {"ms": ms_sw, "achieved": sw_tflops, "frac": (sw_tflops / valu_peak)}},
+                         "note": "FP32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md); algorithmic flops per (layer, g-point) cell: "
+                                 "LW 301, SW 345 (SURVEY.md section 8(d)); `traffic` = 2*FETCH_SIZE + WRITE_SIZE of the committed "
+                                 "rocprofv3 PMC summary (profiles/latest.json), per launch of the dominant kernel"},
             "valu": {"achieved": valu_tflops, "peak": valu_peak, "unit": "TFLOP/s",
                      "frac": valu_tflops / valu_peak,
-                     "algorithmic_flops_per_column": flops / ncol},
+                     "algorithmic_flops_per_column": flops / ncol,
+                     "note": "both kernels of the step together"},
             # the resource that does bind, from the same profile as `traffic`; null without it
             "vmem_pipeline": vmem,
             "kernels": {"lw_solve_kernel_ms": ms_lw, "sw_solve_kernel_ms": ms_sw,
@@ -517,6 +559,28 @@ def main():
                 "config4_fused_step_device": run_leg("config4_fused_step_device", ["--ncol", "4096", "--nlay", "72", "--aerosols",
                                                                                    "--fused-step", "--steps", "50", "--warmup", "5"]),
             }
+            # BASELINE config 4 is a STRONG-scaling case: 4096 columns over 1 -> 8 GPUs, i.e. 4096 / 2048 / 1024 / 512 columns
+            # per GPU.  The driver measures the curve when it has an 8-GPU node; this is its one-GPU prediction: the shard each
+            # rank would own, solved alone on this GPU (columns are independent and there is no collective, so N ranks take
+            # the time of one shard).  min / median of 50 steps.
+            se = {}
+            for n_g in (1, 2, 4, 8):
+                leg = run_leg(f"strong_emulated_{4096 // n_g}", ["--ncol", str(4096 // n_g), "--nlay", "72", "--aerosols",
+                                                                  "--steps", "50", "--warmup", "5"])
+                if "error" not in leg:
+                    leg = {"shard_columns": 4096 // n_g, "min_ms": leg["min_ms"], "median_ms": leg["median_ms"],
+                           "per_gpu_columns_per_s_at_median": (4096 // n_g) / (leg["median_ms"] * 1e-3),
+                           "predicted_job_columns_per_s": 4096 / (leg["median_ms"] * 1e-3)}
+                se[str(n_g)] = leg
+            ok = all("error" not in v for v in se.values())
+            out["strong_emulated"] = {
+                "workload": "BASELINE config 4: 4096 columns x 72 layers, MERRA aerosols, Float32, split over N GPUs",
+                "gpus": se,
+                "predicted_efficiency_vs_1": ({k: v["predicted_job_columns_per_s"] / (int(k) * se["1"]["predicted_job_columns_per_s"])
+                                               for k, v in se.items()} if ok else None),
+                "per_column_rate_512_vs_4096": (se["8"]["per_gpu_columns_per_s_at_median"] / se["1"]["per_gpu_columns_per_s_at_median"]
+                                                if ok else None),
+                "note": "emulated on ONE GPU (no multi-GPU hardware was touched): each entry is the shard of one rank solved alone"}
         # CPU baseline: the plain-C oracle (a port, not the Julia reference) on a bounded sample of
         # the same workload, on this box's host cores.  Rank 0, N = 1 only.
         sample = args.cpu_sample if args.cpu_sample is not None else (512 if world == 1 else 0)
@@ -538,7 +602,14 @@ def main():
             if not args.cpu_sample and tc < 10.0 and n < min(65536, ncol):   # the probe over-estimated: once more, larger
                 n = int(min(n * min(6.0, 15.0 / tc), 65536, ncol))
                 tc = cpu_run(n)
+            cpu_model = None
+            try:
+                with open("/proc/cpuinfo") as fh:
+                    cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+            except OSError:
+                pass
             out["cpu_baseline"] = {"value": n / tc, "unit": "columns/s", "cores": min(O.n_threads(), 32), "kind": "port",
+                                   "threads": min(O.n_threads(), 32), "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
                                    "sample": f"{n} columns of the same workload, oracle/rrtmgp_oracle.c "
                                              f"(gcc -O2, OpenMP over columns), {tc:.1f} s"}
         if args.host:

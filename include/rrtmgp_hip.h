@@ -519,6 +519,13 @@ int rrtmgp_hip_aerosol_lookup_create_multi(const rrtmgp_aerosol_lookup_desc *des
                                            rrtmgp_lookup **out);
 int rrtmgp_hip_workspace_create_multi(const int32_t *device_ids, int ndev, int64_t ncol, int64_t nlay, int32_t ftype,
                                       rrtmgp_workspace **out);
+/* The CPUs next to a GPU's PCIe root: the shard worker of that GPU is bound to them (staging copies of one process at 8 GPUs
+ * only reach their rate from the memory controllers next to each GPU; RRTMGP_HIP_NO_NUMA_BIND=1 leaves the threads unbound).
+ * Reads <RRTMGP_HIP_SYSFS_ROOT or /sys>/bus/pci/devices/<pci_bus_id, lower-cased>/local_cpulist ("0-31,64-95"); writes up to
+ * `cap` CPU numbers and returns how many the list names, or a negative error when there is no such file.  Host logic only:
+ * callable without a GPU (tests/test_sharding.py drives it against a fake sysfs tree). */
+int rrtmgp_hip_local_cpus(const char *pci_bus_id, int32_t *cpus, int cap);
+
 /* Number of shards of a workspace (1 for a single-device workspace). */
 int rrtmgp_hip_workspace_shards(const rrtmgp_workspace *ws);
 

@@ -65,6 +65,7 @@ EXPORTS = {
     "rrtmgp_hip_workspace_create_multi": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.c_int64, C.c_int64, C.c_int32,
                                                     C.POINTER(_P)]),
     "rrtmgp_hip_workspace_shards": (C.c_int, [_P]),
+    "rrtmgp_hip_local_cpus": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.c_int]),
     "rrtmgp_hip_host_register": (C.c_int, [_P, C.c_size_t]),
     "rrtmgp_hip_host_unregister": (C.c_int, [_P]),
     "rrtmgp_hip_host_registered_count": (C.c_int, []),

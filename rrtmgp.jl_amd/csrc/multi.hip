@@ -29,6 +29,39 @@ const rrtmgp_lookup *lookup_on(const rrtmgp_lookup *lk, int device) {
     return nullptr;
 }
 
+// ---- which CPUs sit next to a GPU -------------------------------------------------------------------------------------
+// "<sysfs>/bus/pci/devices/<bus id>/local_cpulist" holds ranges like "0-31,64-95".  Host logic only (no HIP call): exported as
+// rrtmgp_hip_local_cpus so that it can be tested against a fake sysfs tree (RRTMGP_HIP_SYSFS_ROOT, default /sys) on a box
+// whose single GPU never exercises the multi-socket case.
+int parse_cpulist(const char *text, std::vector<int> &cpus) {
+    cpus.clear();
+    std::string line(text ? text : "");
+    char *save = nullptr;
+    for (char *tok = strtok_r(&line[0], ",\n \t", &save); tok; tok = strtok_r(nullptr, ",\n \t", &save)) {
+        int lo = 0, hi = 0;
+        const int k = sscanf(tok, "%d-%d", &lo, &hi);
+        if (k < 1) continue;
+        if (k == 1) hi = lo;
+        if (lo < 0 || hi < lo) continue;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) cpus.push_back(c);
+    }
+    return (int)cpus.size();
+}
+int local_cpus_of(const char *pci_bus_id, std::vector<int> &cpus) {
+    cpus.clear();
+    if (!pci_bus_id || !*pci_bus_id) return -1;
+    std::string id(pci_bus_id);
+    for (char &c : id) c = (char)tolower(c);   // hipDeviceGetPCIBusId prints upper-case hex, sysfs names are lower-case
+    const char *root = getenv("RRTMGP_HIP_SYSFS_ROOT");
+    const std::string path = std::string(root && *root ? root : "/sys") + "/bus/pci/devices/" + id + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    return ok ? parse_cpulist(line, cpus) : 0;
+}
+
 // ---- shard workers ---------------------------------------------------------------------------------------------------
 // One persistent host thread per shard (round 4: shard 0 too — on the calling thread it ran unbound, wherever the host
 // model's thread happened to be), parked on a condition variable between calls: a call costs two notifications per shard instead of a thread spawn + join (multi_run used to
@@ -49,26 +82,12 @@ struct ShardWorkers {
         if (getenv("RRTMGP_HIP_NO_NUMA_BIND")) return;
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
-        for (char *c = bus; *c; c++) *c = (char)tolower(*c);
-        const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
-        FILE *f = fopen(path.c_str(), "r");
-        if (!f) return;
-        char line[4096] = {0};
-        const bool ok = fgets(line, sizeof line, f) != nullptr;
-        fclose(f);
-        if (!ok) return;
+        std::vector<int> cpus;
+        if (local_cpus_of(bus, cpus) <= 0) return;
         cpu_set_t set;
         CPU_ZERO(&set);
-        int n = 0;
-        char *save = nullptr;
-        for (char *tok = strtok_r(line, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {  // "0-31,64-95"
-            int lo = 0, hi = 0;
-            const int k = sscanf(tok, "%d-%d", &lo, &hi);
-            if (k < 1) continue;
-            if (k == 1) hi = lo;
-            for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET(c, &set); n++; }
-        }
-        if (n > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);  // failure (cgroup limits) is harmless
+        for (int c : cpus) CPU_SET(c, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);  // failure (cgroup limits) is harmless
     }
     explicit ShardWorkers(const std::vector<rrtmgp_workspace *> &shards) {
         for (size_t s = 0; s < shards.size(); s++) {
@@ -210,6 +229,14 @@ int rrtmgp_hip_workspace_create_multi(const int32_t *device_ids, int ndev, int64
     }
     *out = head;
     return RRTMGP_OK;
+}
+
+int rrtmgp_hip_local_cpus(const char *pci_bus_id, int32_t *cpus, int cap) {
+    std::vector<int> v;
+    const int n = local_cpus_of(pci_bus_id, v);
+    if (n < 0) return set_error(RRTMGP_EINVAL, "no local_cpulist for this PCI bus id");
+    for (int i = 0; i < n && i < cap && cpus; i++) cpus[i] = v[i];
+    return n;
 }
 
 int rrtmgp_hip_workspace_shards(const rrtmgp_workspace *ws) {

@@ -197,3 +197,32 @@ def test_what_cannot_be_sharded_is_rejected_loudly(tables64):
     # a single-device lookup has a replica on device 0, so it serves a [0, 0] workspace too
     out = rte.solve_lw(rte.TwoStreamLWRTE(ncol, nlay, np.float64, lb2, workspace=ws), as_, rte.DeviceLookup(t["lw"], 0))
     assert np.isfinite(out.flux_up).all()
+
+
+def test_distinct_devices_or_the_documented_error(tables64):
+    """device_ids = [0, 1]: on a box with ONE GPU the library must refuse (no such device) before touching anything; on a box
+    with two or more it is the real multi-GPU path — lookups replicated per device, one worker thread per shard bound next
+    to its GPU — and must give the bits of the single launch.  (The GPU box of this build has one GPU: the second branch
+    runs wherever the driver has more.)"""
+    t = tables64
+    as_, lb, sb = S.make_columns(23, 20, np.float64, seed=12, aerosols=True, night_fraction=0.25, random_cld_frac=True)
+    n = _lib.lib().rrtmgp_hip_device_count()
+    if n < 2:
+        with pytest.raises(_lib.RRTMGPHipError) as e:
+            rte.Workspace(23, 20, np.float64, [0, 1])
+        assert "device" in str(e.value).lower()
+        with pytest.raises(_lib.RRTMGPHipError):
+            rte.DeviceLookup(t["lw"], [0, 1])
+        return
+    ws1, a_lw, a_sw, c_lw, c_sw = _solve_pair(t, as_, lb, sb, 0)
+    a = {n_: a_lw.as_nlev_ncol(n_).copy() for n_ in LWN}, {n_: a_sw.as_nlev_ncol(n_).copy() for n_ in SWN}
+    ids = list(range(min(n, 8)))
+    wsn, b_lw, b_sw, d_lw, d_sw = _solve_pair(t, as_, lb, sb, ids)
+    assert wsn.n_shards == len(ids)
+    for n_ in LWN:
+        np.testing.assert_array_equal(b_lw.as_nlev_ncol(n_), a[0][n_])
+    for n_ in SWN:
+        np.testing.assert_array_equal(b_sw.as_nlev_ncol(n_), a[1][n_])
+    np.testing.assert_array_equal(c_lw, d_lw)
+    np.testing.assert_array_equal(c_sw, d_sw)
+

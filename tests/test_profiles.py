@@ -49,3 +49,27 @@ def test_profile_carries_the_counters_of_traffic_and_vmem_pipeline():
         traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
         assert 2e10 < traffic < 2e11, traffic
     assert bench.vmem_pipeline({"SQ_INSTS_VMEM_RD": 1.0}) is None   # an incomplete profile gives no number
+
+
+def test_roofline_fraction_is_reproducible_from_the_committed_profile():
+    """`roofline.profiled` of the bench line = the dominant kernel's SURVEY section 8(d) flops over the profile's average
+    duration, against the FP32 vector peak: recomputed here from profiles/latest.json alone, and compared with the committed
+    bench line of the round when that line was produced from this profile."""
+    pj, bench = _profile(), _bench()
+    ncol, nlay = bench.NCOL_PER_GPU, bench.NLAY
+    for name, ngpt, cell in (("lw_solve_kernel", 256, bench.LW_FLOPS_PER_CELL), ("sw_solve_kernel", 224, bench.SW_FLOPS_PER_CELL)):
+        ms = pj["kernels"][name]["avg_us"] / 1e3
+        v = bench.kernel_valu(name, ms, ncol, nlay, ngpt)
+        assert abs(v["achieved"] - cell * ngpt * nlay * ncol / (ms * 1e-3) / 1e12) < 1e-9
+        assert abs(v["frac"] - v["achieved"] / bench.VALU_PEAK_TFLOPS) < 1e-12 and 0.15 < v["frac"] < 0.6
+    lines = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_line.json"))
+    with open(os.path.join(ROOT, "profiles", lines[-1])) as fh:
+        line = json.load(fh)
+    r = line.get("roofline") or {}
+    prof = r.get("profiled")
+    if not prof or (r.get("hbm", {}).get("traffic_source") or {}).get("profile") != pj["source"]:
+        pytest.skip("the newest committed bench line was not produced from profiles/latest.json")
+    dom = r["kernel"]
+    v = bench.kernel_valu(dom, pj["kernels"][dom]["avg_us"] / 1e3, ncol, nlay, 256 if dom.startswith("lw") else 224)
+    assert abs(v["frac"] - prof["frac"]) < 1e-9 and r["bound"] == "valu"
+

@@ -225,3 +225,34 @@ def test_bench_layer2_host_leg():
     # state (4 + 2 + 5 layer arrays, 2 level arrays, t_sfc, lat) + boundary conditions, Float32, 32 layers, 16 / 14 bands
     want = 4 * ((4 + 2 + 5) * 32 + 2 * 33 + 2 + 16 + 2 + 2 * 14)
     assert want <= rec["fused"]["h2d_bytes_per_column"] <= want + 8
+
+
+def test_local_cpus_of_a_gpu_from_a_fake_sysfs_tree(tmp_path, monkeypatch):
+    """The NUMA binding of the shard workers (csrc/multi.hip) is host logic: which CPUs the kernel lists next to a GPU's
+    PCIe root.  A one-GPU box never shows the multi-socket case, so it is driven here against a fake sysfs tree:
+    two sockets, range lists with several pieces, single CPUs, upper-case bus ids as hipDeviceGetPCIBusId prints them,
+    a missing device, an empty and a malformed list."""
+    import ctypes as C
+    from rrtmgp_jl_amd import _lib
+    L = _lib.lib()
+    root = tmp_path / "sys"
+    lists = {"0000:05:00.0": "0-3,64-67\n", "0000:c5:00.0": "32-35,96,98-99\n", "0000:e5:00.0": "\n",
+             "0000:f5:00.0": "7,x,9-8,12-13\n"}
+    for dev, text in lists.items():
+        d = root / "bus" / "pci" / "devices" / dev
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(text)
+    monkeypatch.setenv("RRTMGP_HIP_SYSFS_ROOT", str(root))
+
+    def cpus(bus):
+        buf = (C.c_int32 * 64)()
+        n = L.rrtmgp_hip_local_cpus(bus.encode(), buf, 64)
+        return n, list(buf[:max(n, 0)])
+    assert cpus("0000:05:00.0") == (8, [0, 1, 2, 3, 64, 65, 66, 67])
+    assert cpus("0000:C5:00.0") == (7, [32, 33, 34, 35, 96, 98, 99])     # upper-case id, as the HIP runtime prints it
+    assert cpus("0000:e5:00.0")[0] == 0                                    # an empty list binds nothing
+    assert cpus("0000:f5:00.0") == (3, [7, 12, 13])                        # junk and inverted ranges are skipped
+    assert cpus("0000:aa:00.0")[0] < 0 and "local_cpulist" in _lib.last_error()
+    n = L.rrtmgp_hip_local_cpus(b"0000:05:00.0", None, 0)                  # counting only
+    assert n == 8
+    assert L.rrtmgp_hip_local_cpus(None, None, 0) < 0
