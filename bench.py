@@ -116,6 +116,9 @@ def parse_args(argv=None):
                     help="time the Layer-2 step of a host model (update_fluxes! on HOST arrays: prepare_atmosphere! + LW + SW + net, "
                          "AllSkyRadiation): `fused` = ONE call of rrtmgp_hip_update_fluxes (state staged once), `split` = the "
                          "reference's four steps as separate calls (prepare, LW, SW staged separately; net sum on the host)")
+    ap.add_argument("--resident", action="store_true",
+                    help="with --l2 fused: the Layer-2 solver with EVERY array in HBM (RRTMGPSolver(resident=True), what "
+                         "array_type = a device array gives the reference): update_fluxes! stages nothing over PCIe")
     ap.add_argument("--fused-step", action="store_true",
                     help="a step is ONE rrtmgp_hip_update_fluxes call (LW + SW + net sum on one workspace; short steps "
                          "overlap the two solvers) instead of two solve calls")
@@ -189,24 +192,28 @@ def run_l2(args):
     diag = args.clear_sky_diag != "off"
     method = (L2.AllSkyRadiationWithClearSkyDiagnostics if diag else L2.AllSkyRadiation)(aerosol_radiation=args.aerosols)
     s = L2.RRTMGPSolver(method, TEST_PARAMETERS, lb, sb, as_, lookups=L2.LookupBundle(lw, sw, cl, cs, al, asw),
-                        fused=args.l2 == "fused")
+                        fused=args.l2 == "fused", resident=args.resident)
     for _ in range(args.warmup):
         L2.update_fluxes(s)
+    s.lws.ws.synchronize()
     b0 = s.lws.ws.transfer_bytes()
     ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter()
         L2.update_fluxes(s)
+        if args.resident:
+            s.lws.ws.synchronize()   # device arrays: the call is stream-ordered; a host model reads the fluxes after this
         ms.append(1e3 * (time.perf_counter() - ts))
     elapsed = time.perf_counter() - t0
     b1 = s.lws.ws.transfer_bytes()
-    assert np.isfinite(L2.net_flux(s)).all() and (L2.lw_flux_up(s)[0] > 0).all()
+    from rrtmgp_jl_amd.states import to_host
+    assert np.isfinite(to_host(L2.net_flux(s))).all() and (to_host(L2.lw_flux_up(s))[0] > 0).all()
     rec = {"value": ncol * args.steps / elapsed, "unit": "columns/s", "ms_per_step": 1e3 * elapsed / args.steps,
            "min_ms": min(ms), "median_ms": statistics.median(ms), "ncol": ncol, "dtype": args.dtype,
            "h2d_bytes_per_column": (b1[0] - b0[0]) / (ncol * args.steps), "d2h_bytes_per_column": (b1[1] - b0[1]) / (ncol * args.steps),
            "calls_per_step": 1 if args.l2 == "fused" else 3,
-           "workload": f"update_fluxes! on HOST arrays ({args.l2}): prepare_atmosphere! (clip + col_dry) + LW + SW two-stream + net, "
+           "workload": f"update_fluxes! on {'DEVICE-RESIDENT' if args.resident else 'HOST'} arrays ({args.l2}): prepare_atmosphere! (clip + col_dry) + LW + SW two-stream + net, "
                        f"{'AllSkyRadiationWithClearSkyDiagnostics' if diag else 'AllSkyRadiation'}, {ncol} x {nlay}"}
     print(json.dumps(rec))
 
@@ -537,6 +544,10 @@ def main():
                                             "split": run_leg("l2_split", ["--l2", "split"]),
                                             "fused_clear_sky_diag": run_leg("l2_fused_diag", ["--l2", "fused", "--clear-sky-diag", "one-pass"]),
                                             "note": "update_fluxes!(solver) from host arrays, PCIe inclusive; never `value`"}
+            # the same Layer-2 step with every array of the solver resident in HBM (RRTMGPSolver(resident=True)): what the
+            # reference's device array type buys — nothing crosses PCIe inside update_fluxes!
+            out["l2_update_fluxes_device"] = run_leg("l2_device", ["--l2", "fused", "--resident"])
+            out["l2_update_fluxes_device"]["vs_value"] = (out["l2_update_fluxes_device"].get("value", 0.0) / value) if value else None
             precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
             out["precise_f32"] = (run_leg("precise_f32", [], env={"RRTMGP_HIP_LIBRARY": precise}) if os.path.exists(precise)
                                   else {"error": "libhip_rrtmgp_precise.so not built (make -C rrtmgp.jl_amd/csrc precise)"})

@@ -553,6 +553,19 @@ int rrtmgp_hip_host_unregister(void *ptr);
 /* Live registrations (explicit and automatic), for tests. */
 int rrtmgp_hip_host_registered_count(void);
 
+/* ---- caller-owned device arrays ------------------------------------------------------------- */
+
+/* What a host language needs to keep its arrays in HBM without a GPU array package of its own (the Julia glue's
+ * `HIPArray`, ext/RRTMGPHIPExt.jl; the reference gets this from CUDA.jl's CuArray, ext/RRTMGPCUDAExt.jl:1-66): allocation,
+ * release, blocking copies (ordered behind everything queued on the device) and byte fills on device `device`.  A pointer
+ * from rrtmgp_hip_device_malloc is what the descriptors take with `mem = RRTMGP_MEM_DEVICE`.  Not part of the library's own
+ * allocation accounting (rrtmgp_hip_allocation_counts). */
+enum { RRTMGP_COPY_H2D = 1, RRTMGP_COPY_D2H = 2, RRTMGP_COPY_D2D = 3 };
+int rrtmgp_hip_device_malloc(int device, size_t bytes, void **out);
+int rrtmgp_hip_device_free(int device, void *ptr);
+int rrtmgp_hip_memcpy(int device, void *dst, const void *src, size_t bytes, int32_t kind);
+int rrtmgp_hip_memset(int device, void *dst, int32_t byte_value, size_t bytes);
+
 /* ---- allocation accounting (zero-allocation contract, update_fluxes.jl:215-218) ------------ */
 
 /* Device allocations (hipMalloc) and page-locked host memory events (hipHostRegister of caller arrays,

@@ -33,4 +33,39 @@ end
     HIP.retry_parked_slow()
     @test isempty(HIP.PARKED)
 end
+@testset "device-resident arrays (HIPDevice(0; resident = true))" begin
+    import Adapt
+    rdev = HIP.HIPDevice(0; resident = true)
+    @test ClimaComms.array_type(rdev) === HIP.HIPArray
+    @test_throws ErrorException HIP.HIPDevice([0, 0]; resident = true)        # one device only
+    # the array type itself: construction, copies both ways, fill, scalar broadcast, views, Adapt
+    h = rand(Float32, 7, 5)
+    d = HIP.HIPArray(h)
+    @test d isa DenseArray{Float32, 2} && size(d) == (7, 5) && HIP.mem(d) == 1 && HIP.mem(h) == 0
+    @test Array(d) == h
+    @test Array(copy(d)) == h
+    @test all(==(0), Array(fill!(similar(d), 0)))
+    @test all(==(2.5f0), Array(fill!(HIP.HIPArray{Float32}(undef, 3, 4), 2.5)))
+    e = HIP.HIPArray{Float64, 3}(undef, 2, 3, 4); e .= 0
+    @test all(==(0), Array(e))
+    v = view(d, 2:4, :)
+    @test HIP.mem(v) == 1 && pointer(v) == pointer(d) + sizeof(Float32) && strides(v) == (1, 7)
+    @test_throws ErrorException d[1, 1]                                      # no element access over PCIe
+    @test_throws ErrorException (d .= d .+ 1)
+    @test Adapt.adapt(Array, d) == h && Adapt.adapt(HIP.HIPArray, h) isa HIP.HIPArray
+    # the solver: same bits as the host-array solver on the same device, nothing staged, views from the getters
+    for FT in (Float32, Float64)
+        rctx = ClimaComms.SingletonCommsContext(rdev)
+        res = RRTMGP.solve_gray(FT; nlay = 60, ncol = 10, context = rctx).solver
+        hst = RRTMGP.solve_gray(FT; nlay = 60, ncol = 10, context).solver
+        RRTMGP.update_fluxes!(res); RRTMGP.update_fluxes!(hst)
+        @test parent(RRTMGP.net_flux(res)) isa HIP.HIPArray
+        @test Array(parent(RRTMGP.net_flux(res))) == parent(RRTMGP.net_flux(hst))
+        # Adapt round trip of the whole solver (test/standalone.jl:294-335): fresh arrays, same fluxes afterwards
+        back = Adapt.adapt(HIP.HIPArray, Adapt.adapt(Array, res))
+        RRTMGP.update_fluxes!(back)
+        @test Array(parent(RRTMGP.net_flux(back))) == parent(RRTMGP.net_flux(hst))
+        @test (@allocated RRTMGP.update_fluxes!(res)) == 0
+    end
+end
 HIP.release_all!()

@@ -69,6 +69,10 @@ EXPORTS = {
     "rrtmgp_hip_host_register": (C.c_int, [_P, C.c_size_t]),
     "rrtmgp_hip_host_unregister": (C.c_int, [_P]),
     "rrtmgp_hip_host_registered_count": (C.c_int, []),
+    "rrtmgp_hip_device_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(_P)]),
+    "rrtmgp_hip_device_free": (C.c_int, [C.c_int, _P]),
+    "rrtmgp_hip_memcpy": (C.c_int, [C.c_int, _P, _P, C.c_size_t, C.c_int32]),
+    "rrtmgp_hip_memset": (C.c_int, [C.c_int, _P, C.c_int32, C.c_size_t]),
     "rrtmgp_hip_allocation_counts": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rrtmgp_hip_mcica_uniform": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "rrtmgp_hip_eval_primitive": (C.c_int, [C.c_int, C.c_int32, C.c_int32, _P, _P, _P, C.c_int64]),

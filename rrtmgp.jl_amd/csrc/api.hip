@@ -2300,6 +2300,42 @@ int rrtmgp_hip_host_register(void *ptr, size_t bytes) { return host_register_exp
 int rrtmgp_hip_host_unregister(void *ptr) { return host_unregister_explicit(ptr); }
 int rrtmgp_hip_host_registered_count(void) { return host_registered_count(); }
 
+// ---- caller-owned device arrays (a host language without its own GPU array package: ext/RRTMGPHIPExt.jl HIPArray) --------
+// Plain hipMalloc / hipFree / hipMemcpy / hipMemset on the named device: these are the CALLER's arrays, so they do not enter
+// the library's allocation accounting (rrtmgp_hip_allocation_counts is about what a solve allocates).
+int rrtmgp_hip_device_malloc(int device, size_t bytes, void **out) {
+    RR_CHECK(out, "null output pointer");
+    RR_HIP(hipSetDevice(device));
+    RR_HIP(hipMalloc(out, bytes ? bytes : 16));
+    return RRTMGP_OK;
+}
+int rrtmgp_hip_device_free(int device, void *ptr) {
+    if (!ptr) return RRTMGP_OK;
+    RR_HIP(hipSetDevice(device));
+    RR_HIP(hipFree(ptr));
+    return RRTMGP_OK;
+}
+int rrtmgp_hip_memcpy(int device, void *dst, const void *src, size_t bytes, int32_t kind) {
+    RR_CHECK(kind >= RRTMGP_COPY_H2D && kind <= RRTMGP_COPY_D2D, "kind must be 1 (host to device), 2 (device to host) or 3 (device to device)");
+    if (bytes == 0) return RRTMGP_OK;
+    RR_CHECK(dst && src, "null pointer");
+    RR_HIP(hipSetDevice(device));
+    // blocking, and ordered behind everything queued on the device (the solves run on the workspaces' own streams)
+    RR_HIP(hipDeviceSynchronize());
+    RR_HIP(hipMemcpy(dst, src, bytes, kind == RRTMGP_COPY_H2D ? hipMemcpyHostToDevice
+                                      : kind == RRTMGP_COPY_D2H ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    return RRTMGP_OK;
+}
+int rrtmgp_hip_memset(int device, void *dst, int32_t byte_value, size_t bytes) {
+    if (bytes == 0) return RRTMGP_OK;
+    RR_CHECK(dst, "null pointer");
+    RR_HIP(hipSetDevice(device));
+    RR_HIP(hipDeviceSynchronize());
+    RR_HIP(hipMemset(dst, byte_value, bytes));
+    RR_HIP(hipDeviceSynchronize());
+    return RRTMGP_OK;
+}
+
 int rrtmgp_hip_allocation_counts(int64_t *device_allocs, int64_t *device_frees, int64_t *host_registrations) {
     if (device_allocs) *device_allocs = g_dev_allocs.load();
     if (device_frees) *device_frees = g_dev_frees.load();

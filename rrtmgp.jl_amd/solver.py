@@ -18,8 +18,8 @@ from typing import Optional
 import numpy as np
 
 from . import _abi, grid_adaptation, rte
-from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, RRTMGPParameters, SwBCs, VmrGM,
-                     array_dtype, to_host)
+from .states import (AtmosphericState, Flux, GrayAtmosphericState, LwBCs, RRTMGPParameters, SwBCs, VmrGM, _Container,
+                     array_dtype, to_device, to_host)
 
 
 # radiation methods, src/api/radiation_methods.jl:19-70
@@ -67,13 +67,33 @@ class RRTMGPSolver:
                  lookups: Optional[LookupBundle] = None, n_gauss_angles: int = 1, device: int = 0,
                  spectral_fluxes: bool = False, interpolation: str = grid_adaptation.NoInterpolation,
                  bottom_extrapolation: str = grid_adaptation.SameAsInterpolation,
-                 isothermal_boundary_layer: bool = False, center_z=None, face_z=None, fused: bool = True):
+                 isothermal_boundary_layer: bool = False, center_z=None, face_z=None, fused: bool = True,
+                 resident: bool = False):
         """`fused` (default): `update_fluxes` of a spectral method is ONE call of the library (`rrtmgp_hip_update_fluxes`:
-        state staged once, prepare -> LW -> SW -> net on the device); False runs the reference's four steps as four calls."""
+        state staged once, prepare -> LW -> SW -> net on the device); False runs the reference's four steps as four calls.
+
+        `resident=True`: EVERY array of the solver lives in HBM — state, boundary conditions, metric factors, flux / net /
+        clear-sky / per-band buffers (torch tensors, the reversed-shape convention of states.to_device) — what the reference
+        gets from `array_type(device) = CuArray` (ext/RRTMGPCUDAExt.jl:1-66): host arrays handed to the constructor are moved
+        once, `update_fluxes` stages nothing (`Workspace.transfer_bytes() == (0, 0)`), the getters return device VIEWS of the
+        solver's buffers, and `to_host()` / `to_device()` are the Adapt round trip (test/standalone.jl:294-335)."""
+        self.resident = bool(resident)
+        self._torch_device = None
+        if self.resident:
+            import torch
+            if not isinstance(device, int):
+                raise ValueError("a resident solver lives on ONE device: pass its ordinal (sharded workspaces take host arrays)")
+            dev = self._torch_device = torch.device("cuda", device)
+            # (numpy 2 arrays have a `to_device` of their own — the array-API one, "cpu" only: ask for OUR containers by type)
+            mv = lambda x: None if x is None else (x.to_device(dev) if isinstance(x, _Container) else to_device(x, dev))  # noqa: E731
+            as_, bcs_lw, bcs_sw = mv(as_), mv(bcs_lw), mv(bcs_sw)
+            deep_atmosphere_inverse_scaling, center_z, face_z = mv(deep_atmosphere_inverse_scaling), mv(center_z), mv(face_z)
         self.radiation_method, self.params, self.as_ = radiation_method, params, as_
         self.deep_atmosphere_inverse_scaling = deep_atmosphere_inverse_scaling
         self.interpolation, self.bottom_extrapolation = interpolation, bottom_extrapolation
         self.isothermal_boundary_layer, self.center_z, self.face_z = isothermal_boundary_layer, center_z, face_z
+        self._ctor = dict(op_lw=op_lw, op_sw=op_sw, n_gauss_angles=n_gauss_angles, device=device, spectral_fluxes=spectral_fluxes,
+                          fused=fused)
         if interpolation != grid_adaptation.NoInterpolation and (
                 grid_adaptation.requires_z(interpolation) or grid_adaptation.requires_z(bottom_extrapolation)) and (
                 center_z is None or face_z is None):
@@ -107,14 +127,19 @@ class RRTMGPSolver:
         # compute buffers ARE the (nlev, ncol) presentation: update_presentation! is a no-op here
         nb_lw = self.lookups.lookup_lw.n_bnd if spectral_fluxes else 0
         nb_sw = self.lookups.lookup_sw.n_bnd if spectral_fluxes else 0
+        fdev = self._torch_device   # None: host buffers
         self.lws = lw_cls(ncol, nlay, dtype, bcs_lw, n_gauss_angles=n_gauss_angles, workspace=ws,
-                          n_bnd_band_flux=nb_lw)
-        self.sws = sw_cls(ncol, nlay, dtype, bcs_sw, workspace=ws, n_bnd_band_flux=nb_sw)
-        self.net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F")
+                          n_bnd_band_flux=nb_lw, flux_device=fdev)
+        self.sws = sw_cls(ncol, nlay, dtype, bcs_sw, workspace=ws, n_bnd_band_flux=nb_sw, flux_device=fdev)
+
+        def zeros():   # (nlev, ncol) in the reference's index order, where the solver's arrays live
+            a = np.zeros((nlay + 1, ncol), dtype=dtype, order="F")
+            return a if fdev is None else to_device(a, fdev)
+        self.net_flux_buffer = zeros()
         diag = isinstance(radiation_method, AllSkyRadiationWithClearSkyDiagnostics)
-        self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False) if diag else None
-        self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True) if diag else None
-        self.clear_net_flux_buffer = np.zeros((nlay + 1, ncol), dtype=dtype, order="F") if diag else None
+        self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False, device=fdev) if diag else None
+        self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True, device=fdev) if diag else None
+        self.clear_net_flux_buffer = zeros() if diag else None
         self.fused = bool(fused) and not gray
         self._seed = 0       # key of the counter-based McICA stream of the current update_fluxes call
         self._rng_state = 0  # host generator the per-call keys are drawn from (the reference's global `Random` state)
@@ -168,9 +193,60 @@ class RRTMGPSolver:
 
     # ---- update_net_fluxes!, update_fluxes.jl:165-194 ----------------------------------------------
     def update_net_fluxes(self):
-        np.add(self.lws.flux.flux_net, self.sws.flux.flux_net, out=self.net_flux_buffer)
+        if self.resident:
+            import torch
+            add = torch.add
+        else:
+            add = np.add
+        add(self.lws.flux.flux_net, self.sws.flux.flux_net, out=self.net_flux_buffer)
         if self.clear_net_flux_buffer is not None:
-            np.add(self.clear_flux_lw.flux_net, self.clear_flux_sw.flux_net, out=self.clear_net_flux_buffer)
+            add(self.clear_flux_lw.flux_net, self.clear_flux_sw.flux_net, out=self.clear_net_flux_buffer)
+
+    # ---- Adapt round trip (test/standalone.jl:294-335; ext/RRTMGPCUDAExt.jl Adapt rules) -----------------------------
+    _ARRAY_SLOTS = ("net_flux_buffer", "clear_net_flux_buffer", "deep_atmosphere_inverse_scaling", "center_z", "face_z")
+
+    def _adapted(self, resident: bool) -> "RRTMGPSolver":
+        """A solver with fresh copies of every array in the other memory: same method, lookups, options, RNG state and
+        CURRENT contents (state, boundary conditions, fluxes), so that a checkpoint restored on the other side continues
+        where this one stood.  The getters of the result return views of ITS buffers."""
+        if resident and self._torch_device is None:
+            import torch
+            dev = torch.device("cuda", self._ctor["device"] if isinstance(self._ctor["device"], int) else 0)
+        else:
+            dev = self._torch_device
+        mv = (lambda x: None if x is None else (x.to_device(dev) if isinstance(x, _Container) else to_device(x, dev))) if resident else \
+             (lambda x: None if x is None else (x.to_host() if isinstance(x, _Container) else to_host(x)))
+        kw = dict(self._ctor)
+        if resident and not isinstance(kw["device"], int):
+            raise ValueError("a resident solver lives on ONE device")
+        t = RRTMGPSolver(self.radiation_method, self.params, mv(self.lws.bcs), mv(self.sws.bcs), mv(self.as_),
+                         deep_atmosphere_inverse_scaling=mv(self.deep_atmosphere_inverse_scaling), lookups=self.lookups,
+                         interpolation=self.interpolation, bottom_extrapolation=self.bottom_extrapolation,
+                         isothermal_boundary_layer=self.isothermal_boundary_layer, center_z=mv(self.center_z),
+                         face_z=mv(self.face_z), resident=resident, **kw)
+        if resident == self.resident:   # a plain copy: arrays must still be fresh
+            cp = (lambda x: x.clone()) if resident else (lambda x: x.copy(order="F"))
+            t.as_, t.lws.bcs, t.sws.bcs = t.as_._map(cp), t.lws.bcs._map(cp), t.sws.bcs._map(cp)
+        for a, b in ((self.lws.flux, t.lws.flux), (self.sws.flux, t.sws.flux), (self.clear_flux_lw, t.clear_flux_lw),
+                     (self.clear_flux_sw, t.clear_flux_sw), (self.lws.band_flux, t.lws.band_flux),
+                     (self.sws.band_flux, t.sws.band_flux)):
+            if a is not None:
+                for n in ("flux_up", "flux_dn", "flux_net", "flux_dn_dir"):
+                    if getattr(a, n, None) is not None:
+                        setattr(b, n, mv(getattr(a, n)) if resident != self.resident else
+                                (getattr(a, n).clone() if resident else getattr(a, n).copy(order="F")))
+        for n in ("net_flux_buffer", "clear_net_flux_buffer"):
+            v = getattr(self, n)
+            if v is not None:
+                setattr(t, n, mv(v) if resident != self.resident else (v.clone() if resident else v.copy(order="F")))
+        t._seed, t._rng_state = self._seed, self._rng_state
+        return t
+
+    def to_host(self) -> "RRTMGPSolver":
+        return self._adapted(False)
+
+    def to_device(self) -> "RRTMGPSolver":
+        return self._adapted(True)
 
     # ---- update_fluxes!, update_fluxes.jl:223-233 ----------------------------------------------------
     def update_fluxes(self, seedval=None):

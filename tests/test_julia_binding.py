@@ -160,7 +160,9 @@ def test_flux_layout_rule_matches_the_reference_allocation():
             assert entry["wrapper"] == "PermutedDimsArray" and entry["parent_dims"] == ["d2", "d1"]   # (nlev, ncol) parent
         else:
             assert entry["wrapper"] == "none" and entry["parent_dims"] == ["d1", "d2"]                 # (ncol, nlev)
-    assert re.search(r"ClimaComms\.array_type\(::HIPDevice\) = Array", JL)
+    # host arrays by default; `resident = true` switches to the device-resident type, whose flux buffers are plain
+    # (ncol, nlev) arrays by the same rule (`_coalesced_2d` dispatches on the ARRAY type: anything but Array)
+    assert re.search(r"ClimaComms\.array_type\(dev::HIPDevice\) = dev\.resident \? HIPArray : Array", JL)
     ptr_rule = {JLITE.norm_type(m.params[0].type): "".join(t.text for t in m.body if t.kind != "nl")
                 for m in mod.methods if m.name == "flux_ptr"}
     assert ptr_rule == {perm: "ptr(parent(a))", "AbstractMatrix": "ptr(a)"}, ptr_rule
@@ -429,7 +431,7 @@ def test_device_owns_its_handles():
     """`HIPDevice` converts its ids to the ABI's Int32 once and owns a HandleCache; lookups are cached per device set
     (one global table keyed by the lookup alone served the wrong replica set to a second device)."""
     fields = dict(julia_fields_of("HIPDevice"))
-    assert fields == {"ids": "Vector{Int32}", "cache": "HandleCache"}, fields
+    assert fields == {"ids": "Vector{Int32}", "cache": "HandleCache", "resident": "Bool"}, fields
     assert "const LOOKUPS" not in JL and "const WORKSPACES" not in JL
     assert re.search(r"lk_table::Vector\{Any\}", JL)        # keeps the key array alive: its address cannot be reused
 
@@ -459,7 +461,7 @@ _C2JL = {
     "void*": {"P", "Ptr{Cvoid}"}, "constvoid*": {"P", "Ptr{Cvoid}"},
     "rrtmgp_workspace*": {"P", "Ptr{Cvoid}"}, "constrrtmgp_workspace*": {"P", "Ptr{Cvoid}"},
     "rrtmgp_lookup*": {"P", "Ptr{Cvoid}"}, "constrrtmgp_lookup*": {"P", "Ptr{Cvoid}"},
-    "rrtmgp_lookup**": {"Ref{Ptr{Cvoid}}"}, "rrtmgp_workspace**": {"Ref{Ptr{Cvoid}}"},
+    "rrtmgp_lookup**": {"Ref{Ptr{Cvoid}}"}, "rrtmgp_workspace**": {"Ref{Ptr{Cvoid}}"}, "void**": {"Ref{Ptr{Cvoid}}"},
 }
 _STRUCT2JL = {"rrtmgp_gas_lookup_desc": "GasLookupDesc", "rrtmgp_cloud_lookup_desc": "CloudLookupDesc",
               "rrtmgp_aerosol_lookup_desc": "AerosolLookupDesc", "rrtmgp_atmos_state": "AtmosStateDesc",
@@ -643,3 +645,54 @@ def test_pin_walk_is_bounded_and_unpin_parks_refused_arrays():
     assert "xinseen||depth<0" in w and "push!(seen,x)" in w and "depth-1" in w and "@warn" in w and "finalizer(unpin_slow,x)" in w
     assert "rc==0||push!(PARKED,a)" in by["unpin_slow"] and "retry_parked_slow()" in by["unpin_slow"]
     assert "atexit(retry_parked_slow)" in by["__init__"]
+
+
+def test_device_resident_array_type_is_wired_through_every_descriptor():
+    """N4 (round 5): `HIPDevice(id; resident = true)` makes `array_type` a device-resident `HIPArray <: DenseArray` (pointer +
+    extents + finaliser, copies through the library, Adapt rules) and every descriptor takes its memory kind from the arrays
+    it points at (`mem(a)`), never from a literal: a literal 0 next to a device pointer would make the library stage garbage
+    from a device address as if it were host memory."""
+    mod = _module()
+    body = re.search(r"^mutable struct HIPArray\{T, N\} <: DenseArray\{T, N\}\n(.*?)^    function HIPArray", JL, flags=re.S | re.M).group(1)
+    fields = dict((f.strip(), t.strip()) for f, t in (ln.split("::") for ln in body.strip().split("\n")))
+    assert fields == {"ptr": "Ptr{T}", "dims": "NTuple{N, Int}", "device": "Int32"}, fields
+    assert re.search(r"mutable struct HIPArray\{T, N\} <: DenseArray\{T, N\}", JL)
+    assert "finalizer(free_slow, a)" in JL
+    have = {m.name for m in mod.methods}
+    for need in ("Base.size", "Base.pointer", "Base.unsafe_convert", "Base.similar", "Base.copyto!", "Base.Array", "Base.fill!",
+                 "Base.getindex", "Base.setindex!", "Adapt.adapt_storage", "mem", "host_lookup_slow"):
+        assert need in have, need
+    # both directions of Adapt, and both directions + device-to-device of copyto!
+    assert re.search(r"Adapt\.adapt_storage\(::Type\{<:HIPArray\}, x::Array\) = HIPArray\(x\)", JL)
+    assert re.search(r"Adapt\.adapt_storage\(::Type\{<:Array\}, x::HIPArray\) = Array\(x\)", JL)
+    kinds = set(re.findall(r"Int32\((\d)\)\)\s+# RRTMGP_COPY_(\w+)", JL))
+    assert kinds == {("1", "H2D"), ("2", "D2H"), ("3", "D2D")}, kinds
+    header = open(os.path.join(ROOT, "include", "rrtmgp_hip.h")).read()
+    assert re.search(r"RRTMGP_COPY_H2D = 1, RRTMGP_COPY_D2H = 2, RRTMGP_COPY_D2D = 3", header)
+    # the memory-kind trait: host for plain arrays, device for HIPArray, followed through views and wrappers
+    assert re.search(r"mem\(::AbstractArray\) = Int32\(0\)", JL) and re.search(r"mem\(::HIPArray\) = Int32\(1\)", JL)
+    assert re.search(r"mem\(a::Union\{SubArray, PermutedDimsArray, Base\.ReshapedArray\}\) = mem\(parent\(a\)\)", JL)
+    # every descriptor constructor that carries a `mem` (or `metric_mem` / `z_mem`) field fills it with mem(...)
+    toks = [t for t in JLITE.tokenize(JL) if t.kind != "nl"]
+    first_arg = {}
+    for i, t in enumerate(toks):
+        if t.kind == "id" and t.text in ("AtmosStateDesc", "LwBcsDesc", "SwBcsDesc", "FluxOutDesc", "GrayStateDesc") \
+                and toks[i + 1].text == "(" and toks[i - 1].text not in ("struct", "{", "Ref"):
+            close = JLITE._matching(toks, i + 1)
+            args = JLITE._split_top(toks[i + 2:close], ",")
+            first_arg.setdefault(t.text, []).append("".join(x.text for x in args[0]))
+    assert first_arg, first_arg
+    for name, firsts in first_arg.items():
+        assert all(f.startswith("mem(") for f in firsts), (name, firsts)
+    assert re.search(r"SolveOpts\(lw_angles\(s\.lws\), mem\(s\.deep_atmosphere_inverse_scaling\)", JL)
+    assert re.search(r"isothermal_boundary_layer,\s+mem\(center_z\), lookup_lw\.idx_h2o", JL)
+    # the three view-taking methods pass the memory kind of their output array
+    for sym, out in (("rrtmgp_hip_compute_col_gas", "col_dry"), ("rrtmgp_hip_compute_relative_humidity", "rh"),
+                     ("rrtmgp_hip_compute_gray_heating_rate", "hr_lay")):
+        i = JL.index(sym)
+        assert re.search(r"workspace\(dev, ncol, nlay, FT, true\), mem\(%s\), ncol, nlay" % out, JL[i:i + 700]), sym
+    # lookups built with the device array type come down once before the library re-lays them out
+    assert JL.count("lkp = host_lookup_slow(dlkp)") == 3
+    # a resident device is one device
+    assert re.search(r"resident && length\(ids\) != 1", JL)
+

@@ -241,6 +241,8 @@ def _parse_signature(toks: List[Tok], i: int) -> Tuple[str, List[Param], List[Pa
     name = ""
     while toks[j].kind == "id" or (toks[j].kind == "op" and toks[j].text == "."):
         name += toks[j].text; j += 1
+    if toks[j].text == "{":   # a parametric constructor: `HIPArray{T, N}(...)` — the type parameters are not part of the name
+        j = _matching(toks, j) + 1
     assert toks[j].text == "(", (name, toks[j].text, toks[j].line)
     close = _matching(toks, j)
     inner = toks[j + 1:close]
@@ -419,7 +421,10 @@ BASE = {"ccall", "Ref", "Ptr", "Cvoid", "Cint", "Csize_t", "Int32", "Int64", "UI
         "PermutedDimsArray", "GC", "undef", "String", "Integer", "atexit", "values", "foreach", "empty!", "Symbol", "zeros",
         "min", "max", "first", "last", "vec", "Base", "Core", "convert", "ntuple", "all", "any", "isempty",
         "AbstractVector", "push!", "WeakRef", "collect", "eachindex", "isbitstype", "fieldnames", "getfield", "isstructtype",
-        "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray", "Module", "isdefined", "filter!", "in"}
+        "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray", "Module", "isdefined", "filter!", "in",
+        # round 5 (HIPArray): array-type plumbing
+        "prod", "UndefInitializer", "Dims", "throw", "DimensionMismatch", "iszero", "reinterpret", "fill", "fill!", "SubArray",
+        "DenseArray", "Vararg", "map", "similar", "copy"}
 
 
 def _locals_of(m: Method) -> set:
