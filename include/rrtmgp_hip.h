@@ -288,8 +288,11 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws);
 int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream);
 /* Block until everything queued on the workspace stream has finished. */
 int rrtmgp_hip_workspace_synchronize(rrtmgp_workspace *ws);
-/* Milliseconds the solver kernel(s) of the most recent solve took on the
- * device (HIP events on the workspace stream); synchronizes. */
+/* Milliseconds the solver kernel of the most recent LAUNCH of this workspace took on the device (HIP events around the
+ * launch, on the stream it ran on); synchronizes.  After rrtmgp_hip_update_fluxes that is the step's LAST solver launch:
+ * the shortwave kernel (on the workspace's second lane when a short step runs the two solvers side by side) — a per-kernel
+ * breakdown of a fused step comes from two solve calls or from rocprofv3, not from this counter.  After a pipelined host
+ * solve: the last chunk's kernel. */
 int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms);
 
 /* ---- spectral solvers (K1-K4 of SURVEY.md §2.2) -------------------------- */

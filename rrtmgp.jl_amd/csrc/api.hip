@@ -1572,7 +1572,11 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
     const int64_t nrgh = std::min<int64_t>(L.lw_cld ? L.lw_cld->nrghice : INT32_MAX, L.sw_cld ? L.sw_cld->nrghice : INT32_MAX);
     rrtmgp_atmos_state as_lw = *as;
     if (!L.lw_cld) as_lw.cld_cover_lw = nullptr;   // a LW solve without clouds writes no cover: nothing to bring back
-    TRY(stage_state(st, &as_lw, use_cld, use_aero, true, ds, use_cld ? nrgh : 1, StateRW{prep, iso}));
+    // The isothermal boundary layer fills the extra layer of EVERY cloud / aerosol array the state carries, whatever the
+    // radiation method reads (prepare_t does; AllSkyRadiation with aerosol_radiation = false on a state with an
+    // AerosolState): stage them for the preparation even when no lookup asks for them.
+    const bool st_cld = use_cld || (iso && as->cld_frac), st_aero = use_aero || (iso && as->aero_mass);
+    TRY(stage_state(st, &as_lw, st_cld, st_aero, true, ds, use_cld ? nrgh : (st_cld ? (int64_t)INT32_MAX : 1), StateRW{prep, iso}));
     // ... and what only the SW solve writes
     DevState<FT> ds_sw = ds;
     ds_sw.cld_cover = nullptr;
@@ -1602,12 +1606,12 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
             pv.ngas = (int)as->ngas; pv.hs = (int)as->ngas; pv.vmr_h2o = pv.vmr_full + (po->idx_h2o - 1);
         }
         if (iso) {
-            if (use_cld) {
+            if (st_cld) {
                 pv.cld[0] = const_cast<FT *>(ds.cld_r_eff_liq); pv.cld[1] = const_cast<FT *>(ds.cld_r_eff_ice);
                 pv.cld[2] = const_cast<FT *>(ds.cld_path_liq); pv.cld[3] = const_cast<FT *>(ds.cld_path_ice);
                 pv.cld[4] = const_cast<FT *>(ds.cld_frac);
             }
-            if (use_aero) { pv.aero[0] = const_cast<FT *>(ds.aero_size); pv.aero[1] = const_cast<FT *>(ds.aero_mass); }
+            if (st_aero) { pv.aero[0] = const_cast<FT *>(ds.aero_size); pv.aero[1] = const_cast<FT *>(ds.aero_mass); }
         }
         TRY(st.in(po->z_mem, S_ZC, po->center_z, nlay * ncol * E, (const void **)&pv.center_z));
         TRY(st.in(po->z_mem, S_ZF, po->face_z, nlev * ncol * E, (const void **)&pv.face_z));

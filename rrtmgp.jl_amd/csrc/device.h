@@ -1278,8 +1278,12 @@ struct Sweep {
     __device__ __forceinline__ FT *ptr(int lev, int a) const {
         return reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
     }
-    __device__ __forceinline__ void put(int lev, int a, FT v) const { *ptr(lev, a) = v; }
-    __device__ __forceinline__ FT get(int lev, int a) const { return *ptr(lev, a); }
+    __device__ __forceinline__ void put(int lev, int a, FT v) const {
+        if (RR_SWEEP_NT >= 2) __builtin_nontemporal_store(v, ptr(lev, a)); else *ptr(lev, a) = v;
+    }
+    __device__ __forceinline__ FT get(int lev, int a) const {
+        return RR_SWEEP_NT >= 1 ? __builtin_nontemporal_load(ptr(lev, a)) : *ptr(lev, a);
+    }
     // Three values of one level at once (a = 0, or 3 for the clear-sky twin): three rows, three 4-byte accesses per lane.
     // ([level][lane] records, one access per lane and level, were measured twice: 12-byte records in round 3, and 16-byte
     // slots read with one 12-byte load in round 4 — written as 12 bytes or as the whole slot — 3.5 vs 4.1 M columns/s.

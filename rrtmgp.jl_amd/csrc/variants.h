@@ -26,6 +26,10 @@
 #define RR_ACC_ATOMIC 1
 #endif
 
+#ifndef RR_SWEEP_NT  // sweep scratch cache policy: 0 = default; 1 = non-temporal LOADS in the second sweep; 2 = non-temporal loads AND stores
+#define RR_SWEEP_NT 0
+#endif
+
 #define RR_STR2(x) #x
 #define RR_STR(x) RR_STR2(x)
 #ifdef RR_PRECISE_F32
@@ -63,7 +67,13 @@
 #else
 #define RR_HAS_RR_F64_HALF_CHUNK ""
 #endif
-#define RR_BUILD_FLAGS (RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK)
+#if RR_SWEEP_NT != 0
+#define RR_HAS_RR_SWEEP_NT " RR_SWEEP_NT=" RR_STR(RR_SWEEP_NT)
+#define RR_ANY_EXPERIMENT 1
+#else
+#define RR_HAS_RR_SWEEP_NT ""
+#endif
+#define RR_BUILD_FLAGS (RR_HAS_RR_SWEEP_NT RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK)
 #if defined(RR_ANY_EXPERIMENT) && !defined(RR_EXPERIMENTS)
 #error "non-default tuning values are experiments: build them with `make variant NAME=... EXTRA=...` (adds -DRR_EXPERIMENTS), never into the shipped library"
 #endif

@@ -352,8 +352,12 @@ def compute_gray_heating_rate(ws: Workspace, p_lev, flux_net, cp_d: float, grav:
     hr(nlay, ncol) = grav (F_net[k+1] - F_net[k]) / (p_lev[k+1] - p_lev[k]) / cp_d.  `p_lev` / `flux_net` may be the
     getters' domain views (`x[:nlev_domain]`, src/api/getters.jl:42-43): nlay is then one less than the workspace's."""
     nlev, ncol = julia_shape(p_lev)
-    if out is None:
-        out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
+    if out is None:   # a fresh array where the inputs live (the reference's `similar`)
+        if isinstance(p_lev, np.ndarray):
+            out = np.empty((nlev - 1, ncol), dtype=array_dtype(p_lev), order="F")
+        else:
+            import torch
+            out = torch.empty((ncol, nlev - 1), dtype=p_lev.dtype, device=p_lev.device)   # reversed-shape convention
     lev = (nlev, ncol)
     _check_extents(ws, "compute_gray_heating_rate", p_lev=(p_lev, lev), flux_net=(flux_net, lev), hr_lay=(out, (nlev - 1, ncol)))
     (hr, pl, fn), mem, keep = _views(out, p_lev, flux_net)

@@ -143,6 +143,29 @@ def test_fused_step_with_preparation_schemes(tables64, interpolation, bottom, is
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("method,aerosols", [("clear", False), ("allsky", False), ("clear", True)])
+def test_fused_step_fills_the_boundary_layer_of_arrays_the_method_does_not_read(tables64, method, aerosols):
+    """with the isothermal boundary layer the preparation fills the extra layer of EVERY cloud / aerosol array the
+    state carries (grid_adaptation.jl), whatever the radiation method reads.  ClearSkyRadiation on a state with a CloudState,
+    AllSkyRadiation(aerosol_radiation = false) on one with an AerosolState: the state after the fused step must equal the
+    state after the reference's four separate calls, array by array, extra layer included."""
+    fused, split = _pair(tables64, np.float64, method, aerosols, iso=True, interpolation=GA.ArithmeticMean)
+    for s in (fused, split):    # poison the extra layer of everything the preparation has to define
+        for arr in _state_arrays(s.as_).values():
+            if arr.ndim == 2 and arr.shape[0] == s.nlay:
+                arr[-1, :] = np.nan
+            elif arr.ndim == 3 and arr.shape[1] == s.nlay:
+                arr[:, -1, :] = np.nan
+    L2.update_fluxes(fused, 3)
+    L2.update_fluxes(split, 3)
+    a, b = _state_arrays(fused.as_), _state_arrays(split.as_)
+    for name in a:
+        np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+        assert np.isfinite(a[name]).all(), name
+    _assert_same(fused, split, method)
+
+
+@pytest.mark.gpu
 def test_fused_step_matches_the_oracle(tables64):
     """prepare (interpolation, clip, col_dry) + LW + SW + clear-sky pair + net sums against the CPU restatement."""
     t = tables64
