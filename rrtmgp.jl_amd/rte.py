@@ -265,7 +265,10 @@ def update_fluxes(lws: _RTE, sws: _RTE, as_, lookup_lw, lookup_sw, lookup_lw_cld
     lk = [_dev(x, dev) for x in (lookup_lw, lookup_sw, lookup_lw_cld, lookup_sw_cld, lookup_lw_aero, lookup_sw_aero)]
     a = _abi.UpdateFluxesArgs()
     (a.lookup_lw, a.lookup_sw, a.lookup_lw_cld, a.lookup_sw_cld, a.lookup_lw_aero, a.lookup_sw_aero) = [_null(x) for x in lk]
-    ds = as_.desc(lk[2] is not None or lk[3] is not None, lk[4] is not None or lk[5] is not None)
+    # with a preparation step the library gets the WHOLE state: the isothermal boundary layer fills the extra layer of every
+    # cloud / aerosol array the state carries, whatever the radiation method reads (grid_adaptation.jl)
+    full = prepare is not None
+    ds = as_.desc(full or lk[2] is not None or lk[3] is not None, full or lk[4] is not None or lk[5] is not None)
     bl, bs = lws.bcs.desc(), sws.bcs.desc()
     fl, fs = lws.flux.desc(lws.band_flux, clear_flux_lw), sws.flux.desc(sws.band_flux, clear_flux_sw)
     o = _opts(lws.n_gauss_angles, metric_scaling, seed, col_offset)
