@@ -271,7 +271,17 @@ typedef struct rrtmgp_workspace rrtmgp_workspace; /* opaque per-(ncol,nlay,FT) s
 int rrtmgp_hip_device_count(void);
 
 /* One-off table uploads; replace DA(...) in ext/lookup_constructors.jl:83 (LookUpLW),
- * :407 (LookUpSW), :727 (LookUpCld), :18 (LookUpAerosolMerra). */
+ * :407 (LookUpSW), :727 (LookUpCld), :18 (LookUpAerosolMerra).
+ *
+ * LIMITS of this back end (each is checked and refused with RRTMGP_EUNSUPPORTED / RRTMGP_EINVAL and a message, never
+ * silently truncated; rrtmgp-data v1.9 — 256 + 224 g-points, 16 + 14 bands, 9 x 60 x 14 table axes — is inside all of them):
+ *   - n_gpt <= 256 per lookup (one lane per g-point, one workgroup of at most 4 wavefronts per column);
+ *   - n_bnd <= 16 per lookup (the per-(layer, band) LDS records are laid out for 16 bands);
+ *   - table axes n_eta, n_p_ref + 1, n_t_ref <= 255 each (indices travel packed in bytes);
+ *   - a column's LDS records must fit the CU's 160 KB: about 590 layers in Float32, 250 in Float64 (fewer with per-band
+ *     fluxes or the one-pass clear-sky diagnostic), reported by the solve that meets it;
+ *   - ncol < 2^31 and nlay < 4096 per workspace; per-band fluxes need every band, padded to 16 g-points, to fit 256 lanes;
+ *   - every re-laid-out table must be addressable with 32-bit byte offsets (4 GB per lookup). */
 int rrtmgp_hip_gas_lookup_create(const rrtmgp_gas_lookup_desc *desc, int device, rrtmgp_lookup **out);
 int rrtmgp_hip_cloud_lookup_create(const rrtmgp_cloud_lookup_desc *desc, int device, rrtmgp_lookup **out);
 int rrtmgp_hip_aerosol_lookup_create(const rrtmgp_aerosol_lookup_desc *desc, int device, rrtmgp_lookup **out);
