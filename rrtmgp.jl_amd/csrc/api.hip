@@ -9,7 +9,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <mutex>
 #include <thread>
 
@@ -1392,18 +1394,73 @@ static void strided_copy_t(T *dense, T *strided, size_t n0, size_t n1, size_t s0
         else for (size_t i = 0; i < n0; i++) q[i * s0] = d[i];
     }
 }
+// Three helper threads that live as long as the library (the gather used to spawn and join up to three
+// std::threads on EVERY call of a large strided view).  One gather at a time uses them (try_lock): a second caller — the
+// shard workers of a multi-device workspace run concurrently, each bound to its GPU's CPUs — simply copies on its own
+// thread, which is the parallelism a sharded call already has.
+class CopyHelpers {
+    static constexpr int N = 3;
+    std::thread th[N];
+    std::mutex mu, busy;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(size_t, size_t)> *job = nullptr;
+    size_t lo[N] = {0}, hi[N] = {0};
+    unsigned pending = 0, epoch = 0;
+    bool quit = false, started = false;
+    void run(int t) {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_go.wait(lk, [&] { return quit || epoch != seen; });
+            if (quit) return;
+            seen = epoch;
+            const auto *j = job;
+            const size_t a = lo[t], b = hi[t];
+            lk.unlock();
+            if (b > a) (*j)(a, b);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+public:
+    ~CopyHelpers() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        if (started) for (auto &t : th) t.join();
+    }
+    // part(j0, j1) over [0, n): the caller takes the first quarter, the helpers the rest; false = helpers are taken
+    bool parallel(size_t n, const std::function<void(size_t, size_t)> &part) {
+        std::unique_lock<std::mutex> own(busy, std::try_to_lock);
+        if (!own.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!started) { for (int t = 0; t < N; t++) th[t] = std::thread([this, t] { run(t); }); started = true; }
+            for (int t = 0; t < N; t++) { lo[t] = n * (t + 1) / (N + 1); hi[t] = n * (t + 2) / (N + 1); }
+            job = &part; pending = N; epoch++;
+        }
+        cv_go.notify_all();
+        part(0, n / (N + 1));
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        return true;
+    }
+};
+static CopyHelpers g_copy_helpers;
+
 static void strided_copy(void *dense, void *strided, size_t n0, size_t n1, size_t s0, size_t s1, size_t E, bool to_dense) {
-    auto part = [&](size_t j0, size_t j1) {
+    const std::function<void(size_t, size_t)> part = [&](size_t j0, size_t j1) {
         if (E == 4) strided_copy_t<uint32_t>((uint32_t *)dense, (uint32_t *)strided, n0, n1, s0, s1, to_dense, j0, j1);
         else strided_copy_t<uint64_t>((uint64_t *)dense, (uint64_t *)strided, n0, n1, s0, s1, to_dense, j0, j1);
     };
-    // columns are disjoint in both layouts whenever the view itself does not alias (Julia views, numpy basic slices)
-    const size_t nthr = n0 * n1 >= (size_t(1) << 20) ? std::min<size_t>(4, n1) : 1;
-    if (nthr <= 1) { part(0, n1); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 1; t < nthr; t++) th.emplace_back(part, n1 * t / nthr, n1 * (t + 1) / nthr);
-    part(0, n1 / nthr);
-    for (auto &x : th) x.join();
+    // columns are disjoint in both layouts: stage_views refuses written views whose elements overlap
+    if (n0 * n1 >= (size_t(1) << 20) && n1 >= 4 && g_copy_helpers.parallel(n1, part)) return;
+    part(0, n1);
+}
+// distinct (i, j) -> distinct elements?  Sufficient for every view Julia's `view` / numpy basic slicing can make of a dense
+// parent: one stride spans the other dimension entirely.
+static bool view_is_injective(size_t n0, size_t n1, int64_t s0, int64_t s1) {
+    if (n0 <= 1 || n1 <= 1) return (n0 <= 1 || s0 >= 1) && (n1 <= 1 || s1 >= 1);
+    return (s0 >= 1 && (size_t)s1 >= n0 * (size_t)s0) || (s1 >= 1 && (size_t)s0 >= n1 * (size_t)s1);
 }
 struct ViewPack {   // the CPU-gathered views of one call
     rrtmgp_workspace *ws;
@@ -1431,6 +1488,8 @@ static int stage_views(Stager &st, ViewPack &vp, int mem, ViewArg *a, int n, siz
         for (int i = 0; i < n; i++) {
             if (!a[i].v || (pass == 1) != a[i].out) continue;
             RR_CHECK(a[i].v->ptr && a[i].v->stride0 >= 1 && a[i].v->stride1 >= 1, "view2d: null pointer or non-positive stride");
+            RR_CHECK(!a[i].out || view_is_injective(a[i].n0, a[i].n1, a[i].v->stride0, a[i].v->stride1),
+                     "view2d: a written view whose elements overlap (stride1 < n0 * stride0 and stride0 < n1 * stride1) is not supported");
             a[i].ds0 = a[i].v->stride0; a[i].ds1 = a[i].v->stride1;
             if (mem == RRTMGP_MEM_DEVICE) { a[i].dev = (char *)a[i].v->ptr; continue; }
             a[i].ds0 = 1; a[i].ds1 = (int64_t)a[i].n0;   // every host view reaches the kernel dense
