@@ -680,3 +680,112 @@ def compute_relative_humidity(p_lay, t_lay, params, vmr_h2o):
     es = np.exp((17.67 * (t_lay - 273.16)) / (t_lay - 29.65))
     return np.maximum(0.01 * (0.263 * p_lay * q) / es, 0)
 
+
+
+# ---- prepare_atmosphere! (round 5): update_fluxes.jl:252-281, grid_adaptation.jl:60-292, interpolation.jl:148-252 ----
+def _uniform_z_p(T, p1, T1, p2, T2):
+    """uniform_z_p, interpolation.jl:156-157"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(T1 == T2, np.sqrt(p1 * p2), p1 * (p2 / p1) ** (np.log(T / T1) / np.log(T2 / T1)))
+
+
+def _best_fit_p(T, z, p1, T1, z1, p2, T2, z2):
+    """best_fit_p, interpolation.jl:165-167"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(T1 == T2, p1 * (p2 / p1) ** ((z - z1) / (z2 - z1)), p1 * (p2 / p1) ** (np.log(T / T1) / np.log(T2 / T1)))
+
+
+def _interp(mode, z, pd, Td, zd, pu, Tu, zu):
+    """interp!, interpolation.jl:176-197 -> (p, T) of faces between the layers `d` (below) and `u` (above)"""
+    if mode == "arithmetic_mean":
+        return (pd + pu) / 2, (Td + Tu) / 2
+    if mode == "geometric_mean":
+        return np.sqrt(pd * pu), np.sqrt(Td * Tu)
+    if mode == "uniform_z":
+        T = (Td + Tu) / 2
+        return _uniform_z_p(T, pd, Td, pu, Tu), T
+    if mode == "uniform_p":
+        p = (pd + pu) / 2
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return p, Td * (Tu / Td) ** (np.log(p / pd) / np.log(pu / pd))
+    if mode == "best_fit":
+        T = Td + (Tu - Td) * (z - zd) / (zu - zd)
+        return _best_fit_p(T, z, pd, Td, zd, pu, Tu, zu), T
+    raise ValueError(mode)
+
+
+def _extrap(mode, z, p1, T1, z1, p2, T2, z2, Ts, params):
+    """extrap!, interpolation.jl:208-252: a boundary face from the nearest layer (1) and the next one in (2)"""
+    if mode == "arithmetic_mean":
+        return (3 * p1 - p2) / 2, (3 * T1 - T2) / 2
+    if mode == "geometric_mean":
+        return np.sqrt(p1 ** 3 / p2), np.sqrt(T1 ** 3 / T2)
+    if mode == "uniform_z":
+        T = (3 * T1 - T2) / 2
+        return _uniform_z_p(T, p1, T1, p2, T2), T
+    if mode == "uniform_p":
+        p = (3 * p1 - p2) / 2
+        with np.errstate(invalid="ignore", divide="ignore"):   # a negative extrapolated pressure gives NaN, as in Julia
+            return p, T1 * (T2 / T1) ** (np.log(p / p1) / np.log(p2 / p1))
+    if mode == "best_fit":
+        T = T1 + (T2 - T1) * (z - z1) / (z2 - z1)
+        return _best_fit_p(T, z, p1, T1, z1, p2, T2, z2), T
+    if mode == "use_surface_temp_at_bottom":
+        T = Ts + 0 * T1
+        return p1 * (T / T1) ** (params.cp_d / params.R_d), T
+    if mode == "hydrostatic_bottom":
+        T = T1 + params.grav / params.cp_d * (z1 - z)
+        return p1 * (T / T1) ** (params.cp_d / params.R_d), T
+    raise ValueError(mode)
+
+
+def prepare_atmosphere(as_, params, interpolation, bottom_extrapolation, isothermal_boundary_layer, center_z, face_z,
+                       p_min, t_min, t_max, idx_h2o):
+    """prepare_atmosphere! of a spectral state on numpy arrays, IN PLACE: interpolate_levels! -> add_isothermal_boundary_layer!
+    -> clip! -> update_concentrations! (= compute_col_gas!).  Scheme names as rrtmgp_jl_amd.grid_adaptation spells them."""
+    p_lev, t_lev = as_.p_lev, as_.t_lev
+    p_lay, t_lay, rh = as_.layerdata[1], as_.layerdata[2], as_.layerdata[3]
+    iso = bool(isothermal_boundary_layer)
+    n = p_lay.shape[0] - int(iso)          # domain layers
+    if interpolation != "none":
+        zl = center_z if center_z is not None else np.zeros_like(p_lay)
+        zf = face_z if face_z is not None else np.zeros_like(p_lev)
+        # interior faces 2..nlay (1-based) from the layers below and above
+        p, T = _interp(interpolation, zf[1:n], p_lay[0:n - 1], t_lay[0:n - 1], zl[0:n - 1], p_lay[1:n], t_lay[1:n], zl[1:n])
+        p_lev[1:n], t_lev[1:n] = p, T
+        # top face from the two highest layers, bottom face by its own scheme
+        p, T = _extrap(interpolation, zf[n], p_lay[n - 1], t_lay[n - 1], zl[n - 1], p_lay[n - 2], t_lay[n - 2], zl[n - 2],
+                       as_.t_sfc, params)
+        p_lev[n], t_lev[n] = p, T
+        mode = interpolation if bottom_extrapolation == "same_as_interpolation" else bottom_extrapolation
+        p, T = _extrap(mode, zf[0], p_lay[0], t_lay[0], zl[0], p_lay[1], t_lay[1], zl[1], as_.t_sfc, params)
+        p_lev[0], t_lev[0] = p, T
+    if iso:   # add_isothermal_boundary_layer!, grid_adaptation.jl:131-147
+        p_lay[-1] = (p_lev[-2] + p_min) / 2
+        p_lev[-1] = p_min
+        t_lay[-1] = t_lev[-2]
+        t_lev[-1] = t_lev[-2]
+        rh[-1] = rh[-2]
+        v = as_.vmr
+        if hasattr(v, "vmr_h2o"):
+            v.vmr_h2o[-1] = v.vmr_h2o[-2]; v.vmr_o3[-1] = v.vmr_o3[-2]
+        else:
+            v.vmr[:, -1] = v.vmr[:, -2]
+        cs = as_.cloud_state
+        if cs is not None:
+            for name in ("cld_r_eff_liq", "cld_r_eff_ice", "cld_path_liq", "cld_path_ice", "cld_frac"):
+                a = getattr(cs, name); a[-1] = a[-2]
+        ae = as_.aerosol_state
+        if ae is not None:
+            ae.aero_size[:, -1] = ae.aero_size[:, -2]; ae.aero_mass[:, -1] = ae.aero_mass[:, -2]
+    # clip!, grid_adaptation.jl:232-262
+    h2o = as_.vmr.vmr_h2o if hasattr(as_.vmr, "vmr_h2o") else as_.vmr.vmr[idx_h2o - 1]
+    np.maximum(h2o, 0, out=h2o)
+    np.maximum(p_lay, p_min, out=p_lay)
+    np.maximum(p_lev, p_min, out=p_lev)
+    if t_min is not None and t_max is not None:
+        np.clip(t_lay, t_min, t_max, out=t_lay)
+        np.clip(t_lev, t_min, t_max, out=t_lev)
+    # update_concentrations!, grid_adaptation.jl:278-292
+    as_.layerdata[0] = compute_col_gas(p_lev, params, h2o, as_.lat)
+    return as_

@@ -112,17 +112,21 @@ __global__ void __launch_bounds__(64) prepare_kernel(const PrepView<FT> v, const
         __syncthreads();
     }
     if (a.steps & RRTMGP_PREP_CLIP) {  // clip!, :215-258 (gray: pressures only)
+        // Julia's max(x, lo) and clamp(x, lo, hi) keep a NaN x (a face extrapolated to a negative pressure gives NaN through
+        // log, interpolation.jl:228): a bad input must surface as NaN fluxes, not as a value clamped to a table bound
+        auto jl_max = [](FT x, FT lo) { return x != x ? x : (x > lo ? x : lo); };
+        auto jl_clamp = [](FT x, FT lo, FT hi) { return x > hi ? hi : (x < lo ? lo : x); };
         for (int k = lane; k < nlev_all; k += 64) {
             if (k < nlay_all) {
                 if (v.vmr_h2o) {
                     FT &h = v.vmr_h2o[(size_t)v.hs * (lay0 + k)];
-                    h = m_max(h, FT(0));
+                    h = jl_max(h, FT(0));
                 }
-                p_lay[ls * k] = m_max(p_lay[ls * k], a.p_min);
-                if (a.clamp_t) t_lay[ls * k] = m_min(m_max(t_lay[ls * k], a.t_min), a.t_max);
+                p_lay[ls * k] = jl_max(p_lay[ls * k], a.p_min);
+                if (a.clamp_t) t_lay[ls * k] = jl_clamp(t_lay[ls * k], a.t_min, a.t_max);
             }
-            p_lev[k] = m_max(p_lev[k], a.p_min);
-            if (a.clamp_t) t_lev[k] = m_min(m_max(t_lev[k], a.t_min), a.t_max);
+            p_lev[k] = jl_max(p_lev[k], a.p_min);
+            if (a.clamp_t) t_lev[k] = jl_clamp(t_lev[k], a.t_min, a.t_max);
         }
         __syncthreads();
     }

@@ -188,6 +188,27 @@ def _assert_state_close(got, ref, rtol):
                 np.testing.assert_allclose(x, y, rtol=rtol, atol=0, equal_nan=True, err_msg=f"{c}.{f}")
 
 
+@pytest.mark.parametrize("vmr_kind", ["gm", "full"])
+def test_numpy_restatement_of_prepare_atmosphere_agrees_with_the_c_oracle(tables64, vmr_kind):
+    """N2 twice (round 5): oracle/np_oracle.py restates interpolate_levels! / add_isothermal_boundary_layer! / clip! /
+    update_concentrations! from the Julia sources (grid_adaptation.jl:60-292, interpolation.jl:148-252) with no code shared
+    with the C oracle; every interpolation scheme x bottom scheme x isothermal layer, both Vmr kinds, Float64."""
+    from oracle import np_oracle as NP
+    lw = tables64["lw"]
+    for interp in SCHEMES + [GA.NoInterpolation]:
+        for bot in BOTTOMS:
+            for iso in (False, True):
+                as_, zc, zf = _perturbed_columns(np.float64, vmr_kind, iso)
+                ref = copy.deepcopy(as_)
+                kw = dict(interpolation=interp, bottom_extrapolation=bot, isothermal_boundary_layer=iso, center_z=zc,
+                          face_z=zf)
+                oracle.prepare_atmosphere(ref, TEST_PARAMETERS, _abi.PREP_ALL, p_min=lw.p_ref_min, t_min=lw.t_ref_min,
+                                          t_max=lw.t_ref_max, idx_h2o=lw.idx_h2o, **kw)
+                NP.prepare_atmosphere(as_, TEST_PARAMETERS, interp, bot, iso, zc, zf, lw.p_ref_min, lw.t_ref_min,
+                                      lw.t_ref_max, lw.idx_h2o)
+                _assert_state_close(as_, ref, 1e-13)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("FT,rtol", [(np.float64, 1e-13), (np.float32, 1e-4)])
 @pytest.mark.parametrize("vmr_kind", ["gm", "full"])
