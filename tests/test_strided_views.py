@@ -214,24 +214,7 @@ def test_a_strided_view_moves_its_own_elements_once():
     u1, d1 = ws.transfer_bytes()
     np.testing.assert_allclose(ld[0], want, rtol=1e-5)
     np.testing.assert_array_equal(ld[1:], before[1:])
-    # the helper threads are persistent (ADVICE r4: three std::threads were spawned and joined per call): many calls, and
-    # two workspaces gathering at the same time from two Python threads (the second finds the helpers taken and copies alone)
-    import threading
-    n_before = threading.active_count()
-    for _ in range(5):
-        rte.compute_col_gas(ws, p_lev, params, h2o3[1], None, out=ld[0])
-    ws2 = rte.Workspace(ncol, nlay, ft)
-    ld2 = np.asfortranarray(rng.uniform(1.0, 2.0, (4, nlay, ncol)).astype(ft))
-    res = []
 
-    def work(w, dst):
-        for _ in range(4):
-            rte.compute_col_gas(w, p_lev, params, h2o3[1], None, out=dst[0])
-        res.append(np.array_equal(dst[0], ld[0]) or np.allclose(dst[0], want, rtol=1e-5))
-    ts = [threading.Thread(target=work, args=(ws, ld)), threading.Thread(target=work, args=(ws2, ld2))]
-    [t.start() for t in ts]; [t.join() for t in ts]
-    assert res == [True, True] and threading.active_count() == n_before
-    np.testing.assert_allclose(ld2[0], want, rtol=1e-5)
     E = 4
     up_alg = (nlay + 1) * ncol * E + nlay * ncol * E + ncol * E        # p_lev + vmr_h2o + lat
     dn_alg = nlay * ncol * E                                           # col_dry
@@ -288,3 +271,21 @@ def test_large_strided_views_are_gathered_by_several_threads():
     want = O.compute_col_gas(p_lev, params, np.asfortranarray(h2o3[1]), None)
     np.testing.assert_allclose(ld[0], want, rtol=1e-5)
     np.testing.assert_array_equal(ld[1:], before[1:])
+    # the helper threads are persistent (ADVICE r4: three std::threads were spawned and joined per call): many calls, and
+    # two workspaces gathering at the same time from two Python threads (the second finds the helpers taken and copies alone)
+    import threading
+    n_before = threading.active_count()
+    for _ in range(5):
+        rte.compute_col_gas(ws, p_lev, params, h2o3[1], None, out=ld[0])
+    ws2 = rte.Workspace(ncol, nlay, ft)
+    ld2 = np.asfortranarray(rng.uniform(1.0, 2.0, (4, nlay, ncol)).astype(ft))
+    res = []
+
+    def work(w, dst):
+        for _ in range(4):
+            rte.compute_col_gas(w, p_lev, params, h2o3[1], None, out=dst[0])
+        res.append(np.array_equal(dst[0], ld[0]) or np.allclose(dst[0], want, rtol=1e-5))
+    ts = [threading.Thread(target=work, args=(ws, ld)), threading.Thread(target=work, args=(ws2, ld2))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert res == [True, True] and threading.active_count() == n_before
+    np.testing.assert_allclose(ld2[0], want, rtol=1e-5)
