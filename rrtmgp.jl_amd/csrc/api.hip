@@ -239,16 +239,17 @@ static int bounce_ensure(rrtmgp_workspace *ws, size_t bytes) {
     return RRTMGP_OK;
 }
 
-int scratch_ensure(rrtmgp_workspace *ws, size_t bytes) {
-    if (ws->scratch.bytes >= bytes && ws->scratch.ptr) return RRTMGP_OK;
-    if (ws->scratch.ptr) {
-        RR_HIP(hipStreamSynchronize(ws->stream));
-        RR_HIP(rr_free(ws->scratch.ptr));
+int scratch_ensure(rrtmgp_workspace *ws, size_t bytes, const Lane *lane) {
+    DeviceBuffer &b = lane ? *lane->scratch : ws->scratch;
+    if (b.bytes >= bytes && b.ptr) return RRTMGP_OK;
+    if (b.ptr) {
+        RR_HIP(hipStreamSynchronize(lane ? lane->stream : ws->stream));   // its last user
+        RR_HIP(rr_free(b.ptr));
     }
-    ws->scratch.ptr = nullptr;
-    ws->scratch.bytes = 0;
-    RR_HIP(rr_malloc(&ws->scratch.ptr, bytes));
-    ws->scratch.bytes = bytes;
+    b.ptr = nullptr;
+    b.bytes = 0;
+    RR_HIP(rr_malloc(&b.ptr, bytes));
+    b.bytes = bytes;
     return RRTMGP_OK;
 }
 
@@ -1748,26 +1749,26 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
         TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, nullptr, L.lw_aero, ds, emis, inc, inc_ld, c, n_angles, seed, coff, L.lw_max_int));
     }
     TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, L.lw_cld, L.lw_aero, ds, emis, inc, inc_ld, fl_lw, n_angles, seed, coff, L.lw_max_int));
-    auto sw_lane = [&]() -> int {
+    auto sw_lane = [&](const Lane *lane) -> int {
         if (diag_sw && band_sw) {
             const DevFlux<FT> c = clear_first(fl_sw);
             DevState<FT> dc = ds_sw;
             dc.aod_sw_ext = dc.aod_sw_sca = nullptr;   // the all-sky solve writes the same values
-            TRY(launch_sw<FT>(ws, 1, *L.sw, nullptr, L.sw_aero, dc, mu0, toa, adir, adif, c, seed, coff, L.sw_max_int));
+            TRY(launch_sw<FT>(ws, 1, *L.sw, nullptr, L.sw_aero, dc, mu0, toa, adir, adif, c, seed, coff, L.sw_max_int, lane));
         }
-        return launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int);
+        return launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int, lane);
     };
     if (overlap) {
         // fork: the second lane starts behind everything queued so far (uploads, preparation), NOT behind the LW kernels
-        // that were queued after `fork_at`; join: the net sums and the downloads wait for it
-        std::swap(ws->stream, ws->alt_stream); std::swap(ws->scratch, ws->alt_scratch);
-        int rc = hipStreamWaitEvent(ws->stream, ws->ev_k[0], 0) == hipSuccess ? sw_lane() : set_error(RRTMGP_EHIP, "hipStreamWaitEvent");
-        if (rc == RRTMGP_OK && hipEventRecord(ws->ev_k[1], ws->stream) != hipSuccess) rc = set_error(RRTMGP_EHIP, "hipEventRecord");
-        std::swap(ws->stream, ws->alt_stream); std::swap(ws->scratch, ws->alt_scratch);
-        TRY(rc);
+        // that were queued after `fork_at`; join: the net sums and the downloads wait for it.  The lane is handed to the
+        // launches explicitly (its own stream, its own sweep scratch): the workspace's fields stay what they are.
+        const Lane second{ws->alt_stream, &ws->alt_scratch};
+        RR_HIP(hipStreamWaitEvent(second.stream, ws->ev_k[0], 0));
+        TRY(sw_lane(&second));
+        RR_HIP(hipEventRecord(ws->ev_k[1], second.stream));
         RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_k[1], 0));
     } else {
-        TRY(sw_lane());
+        TRY(sw_lane(nullptr));
     }
     if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
     if (clear_net) TRY(launch_net_sum<FT>(ws, lw_clear_net, sw_clear_net, clear_net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));

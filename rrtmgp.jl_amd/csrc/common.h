@@ -197,7 +197,14 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 // ensure ws->stage[slot] holds at least `bytes`
 int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes);
-int scratch_ensure(rrtmgp_workspace *ws, size_t bytes);
+// A lane = the stream a launch goes to and the sweep scratch it uses.  Every launch helper takes one explicitly where the
+// workspace has two (the fused step runs short SW solves on the second lane): nothing swaps fields of the workspace in and
+// out around a call any more.  nullptr = the workspace's main lane.
+struct Lane {
+    hipStream_t stream;
+    DeviceBuffer *scratch;
+};
+int scratch_ensure(rrtmgp_workspace *ws, size_t bytes, const Lane *lane = nullptr);
 
 // every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
 hipError_t rr_malloc(void **p, size_t bytes);
@@ -228,7 +235,7 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
 template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
               const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
-              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_minor);
+              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_minor, const Lane *lane = nullptr);
 
 struct GrayArgs {
     int otp_kind;

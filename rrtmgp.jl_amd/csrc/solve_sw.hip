@@ -383,7 +383,9 @@ int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, c
 template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
               const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
-              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_int) {
+              const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_int, const Lane *lane) {
+    const Lane main_lane{ws->stream, &ws->scratch};
+    const Lane &ln = lane ? *lane : main_lane;   // where this launch goes: the workspace's main lane, or the one it was handed
     SwArgs<FT> a{};
     a.lk = lk;
     if (cld) a.cld = *cld;
@@ -461,23 +463,24 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     if (grid < 0) return grid;
     const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
-    int rc = scratch_ensure(ws, sweep_bytes + 256);
+    int rc = scratch_ensure(ws, sweep_bytes + 256, &ln);
     if (rc) return rc;
-    a.scratch = (FT *)ws->scratch.ptr;
-    a.queue = (int *)((char *)ws->scratch.ptr + sweep_bytes);
-    RR_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), ws->stream));
-    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
+    a.scratch = (FT *)ln.scratch->ptr;
+    a.queue = (int *)((char *)ln.scratch->ptr + sweep_bytes);
+    RR_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), ln.stream));
+    // (last_kernel_ms = the workspace's LAST solver launch, whichever lane it ran on: include/rrtmgp_hip.h)
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ln.stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ln.stream, a);
     RR_HIP(hipGetLastError());
-    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_stop, ws->stream));
+    if (ws->timed) RR_HIP(hipEventRecord(ws->ev_stop, ln.stream));
     return RRTMGP_OK;
 }
 
 template int launch_sw<float>(rrtmgp_workspace *, int, const DevGas<float> &, const DevCld<float> *,
                               const DevAero<float> *, const DevState<float> &, const float *, const float *,
-                              const float *, const float *, const DevFlux<float> &, uint64_t, int64_t, int);
+                              const float *, const float *, const DevFlux<float> &, uint64_t, int64_t, int, const Lane *);
 template int launch_sw<double>(rrtmgp_workspace *, int, const DevGas<double> &, const DevCld<double> *,
                                const DevAero<double> *, const DevState<double> &, const double *, const double *,
-                               const double *, const double *, const DevFlux<double> &, uint64_t, int64_t, int);
+                               const double *, const double *, const DevFlux<double> &, uint64_t, int64_t, int, const Lane *);
 
 }  // namespace rrtmgp
