@@ -253,6 +253,22 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes, const Lane *lane) {
     return RRTMGP_OK;
 }
 
+int queue_ensure(rrtmgp_workspace *ws, int lane_idx, int **out) {
+    int *&q = ws->col_queue[lane_idx & 1];
+    if (!q) {
+        void *p = nullptr;
+        RR_HIP(rr_malloc(&p, 256));
+        // once: the zeroing must be COMPLETE before any stream of this workspace launches a kernel that reads the counters
+        // (the workspace streams are non-blocking: nothing orders them behind the null stream a plain hipMemset runs on;
+        // an unordered first launch read uninitialised counters — a negative "next column" — and faulted)
+        RR_HIP(hipMemset(p, 0, 256));
+        RR_HIP(hipDeviceSynchronize());
+        q = (int *)p;
+    }
+    *out = q;
+    return RRTMGP_OK;
+}
+
 // Number of workgroups for a one-workgroup-per-column kernel: every column gets its
 // own group up to a few resident generations per CU, then groups stride over columns.
 // Persistent grid of the column kernels: exactly the workgroups that are resident at once
@@ -1069,7 +1085,7 @@ static bool host_pipeline_applies(const rrtmgp_atmos_state *as, int bcs_mem, con
 // workspace's compute stream — the two-solve host leg (two workspaces) fell from 38 to 42-45 ms when every pipelined
 // workspace also owned the second compute lane of the short Layer-2 step (tools/experiments/host_regress_ab.sh).
 static int fork_join_events(rrtmgp_workspace *ws) {
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (!ws->ev_k[i]) RR_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
     return RRTMGP_OK;
 }
@@ -1585,10 +1601,11 @@ __global__ void net_sum_kernel(const FT *a, const FT *b, FT *out, int ncol, int 
     out[i] = a[ia] + b[ib];
 }
 template <typename FT>
-static int launch_net_sum(rrtmgp_workspace *ws, const FT *a, const FT *b, FT *out, size_t ncol, size_t nlev, int layout, int lda, int ldb) {
+static int launch_net_sum(rrtmgp_workspace *ws, const FT *a, const FT *b, FT *out, size_t ncol, size_t nlev, int layout, int lda, int ldb,
+                          hipStream_t stream = nullptr) {
     const size_t n = ncol * nlev;
-    hipLaunchKernelGGL(net_sum_kernel<FT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ws->stream, a, b, out, (int)ncol, (int)nlev,
-                       layout, lda, ldb);
+    hipLaunchKernelGGL(net_sum_kernel<FT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream ? stream : ws->stream, a, b, out,
+                       (int)ncol, (int)nlev, layout, lda, ldb);
     RR_HIP(hipGetLastError());
     return RRTMGP_OK;
 }
@@ -1743,12 +1760,13 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
         return c;
     };
     FT *lw_clear_net = fl_lw.clear_net, *sw_clear_net = fl_sw.clear_net;
-    if (overlap) RR_HIP(hipEventRecord(ws->ev_k[0], ws->stream));  // `fork_at`
-    if (diag_lw && (!twostream_lw || band_lw)) {
-        const DevFlux<FT> c = clear_first(fl_lw);
-        TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, nullptr, L.lw_aero, ds, emis, inc, inc_ld, c, n_angles, seed, coff, L.lw_max_int));
-    }
-    TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, L.lw_cld, L.lw_aero, ds, emis, inc, inc_ld, fl_lw, n_angles, seed, coff, L.lw_max_int));
+    auto lw_lane = [&]() -> int {
+        if (diag_lw && (!twostream_lw || band_lw)) {
+            const DevFlux<FT> c = clear_first(fl_lw);
+            TRY(launch_lw<FT>(ws, twostream_lw, *L.lw, nullptr, L.lw_aero, ds, emis, inc, inc_ld, c, n_angles, seed, coff, L.lw_max_int));
+        }
+        return launch_lw<FT>(ws, twostream_lw, *L.lw, L.lw_cld, L.lw_aero, ds, emis, inc, inc_ld, fl_lw, n_angles, seed, coff, L.lw_max_int);
+    };
     auto sw_lane = [&](const Lane *lane) -> int {
         if (diag_sw && band_sw) {
             const DevFlux<FT> c = clear_first(fl_sw);
@@ -1758,20 +1776,44 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
         }
         return launch_sw<FT>(ws, 1, *L.sw, L.sw_cld, L.sw_aero, ds_sw, mu0, toa, adir, adif, fl_sw, seed, coff, L.sw_max_int, lane);
     };
+    auto net_sums = [&](hipStream_t stream) -> int {
+        if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld, stream));
+        if (clear_net) TRY(launch_net_sum<FT>(ws, lw_clear_net, sw_clear_net, clear_net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld, stream));
+        return RRTMGP_OK;
+    };
     if (overlap) {
-        // fork: the second lane starts behind everything queued so far (uploads, preparation), NOT behind the LW kernels
-        // that were queued after `fork_at`; join: the net sums and the downloads wait for it.  The lane is handed to the
-        // launches explicitly (its own stream, its own sweep scratch): the workspace's fields stay what they are.
-        const Lane second{ws->alt_stream, &ws->alt_scratch};
+        // Two lanes:   main lane  : record fork, LW kernel(s) ................. [wait join] net sums
+        //              second lane: [wait fork] SW kernel(s), record join
+        // The fork sits behind everything queued so far (uploads, preparation).  No memset is queued in front of either kernel
+        // (queue_release): 512 columns x 72 with aerosols 226 -> 220 us per step.  The lane is handed to the launches
+        // explicitly: the workspace's fields stay what they are.  Two other orders were measured from the GPU-side timeline of
+        // that step (tools/experiments/small_step_timeline.sh, small_step_ab.sh, profiles/r05_small_step_ab.txt) and are kept
+        // behind RRTMGP_HIP_STEP_ORDER for A/B: 1 = net sums on the second lane behind SW, waiting only for an "LW done" event
+        // (one exposed cross-stream wait instead of two: 230 us, worse), 2 = also SW, the longer kernel, queued first (226 us).
+        const Lane second{ws->alt_stream, &ws->alt_scratch, 1};
+        static const int order = getenv("RRTMGP_HIP_STEP_ORDER") ? atoi(getenv("RRTMGP_HIP_STEP_ORDER")) : 0;   // A/B switch
+        RR_HIP(hipEventRecord(ws->ev_k[0], ws->stream));   // fork
         RR_HIP(hipStreamWaitEvent(second.stream, ws->ev_k[0], 0));
-        TRY(sw_lane(&second));
-        RR_HIP(hipEventRecord(ws->ev_k[1], second.stream));
-        RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_k[1], 0));
+        if (order == 0) {          // (shipped) LW queued first, net sums on the main lane behind the join
+            TRY(lw_lane());
+            TRY(sw_lane(&second));
+            RR_HIP(hipEventRecord(ws->ev_k[1], second.stream));
+            RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_k[1], 0));
+            TRY(net_sums(nullptr));
+        } else {
+            if (order == 1) { TRY(lw_lane()); TRY(sw_lane(&second)); }   // LW first, net sums on the second lane
+            else { TRY(sw_lane(&second)); TRY(lw_lane()); }
+            RR_HIP(hipEventRecord(ws->ev_k[2], ws->stream));   // LW done
+            RR_HIP(hipStreamWaitEvent(second.stream, ws->ev_k[2], 0));
+            TRY(net_sums(second.stream));
+            RR_HIP(hipEventRecord(ws->ev_k[1], second.stream));   // join
+            RR_HIP(hipStreamWaitEvent(ws->stream, ws->ev_k[1], 0));
+        }
     } else {
+        TRY(lw_lane());
         TRY(sw_lane(nullptr));
+        TRY(net_sums(nullptr));
     }
-    if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
-    if (clear_net) TRY(launch_net_sum<FT>(ws, lw_clear_net, sw_clear_net, clear_net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
     return chunk && !st.packed ? RRTMGP_OK : st.finish();
 }
 
@@ -1937,10 +1979,12 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
         if (ws->ev_in[i]) (void)hipEventDestroy(ws->ev_in[i]);
         if (ws->ev_k[i]) (void)hipEventDestroy(ws->ev_k[i]);
     }
+    if (ws->ev_k[2]) (void)hipEventDestroy(ws->ev_k[2]);
     if (ws->copy_stream) (void)hipStreamDestroy(ws->copy_stream);
     if (ws->alt_stream) (void)hipStreamDestroy(ws->alt_stream);
     if (ws->scratch.ptr) (void)rr_free(ws->scratch.ptr);
     if (ws->alt_scratch.ptr) (void)rr_free(ws->alt_scratch.ptr);
+    for (int *q : ws->col_queue) if (q) (void)rr_free(q);
     if (ws->bounce_h) (void)hipHostFree(ws->bounce_h);
     if (ws->bounce_d) (void)rr_free(ws->bounce_d);
     if (ws->ev_start) (void)hipEventDestroy(ws->ev_start);

@@ -161,7 +161,8 @@ struct rrtmgp_workspace {
     // scratch while the LW kernels run on `stream`, so that one solver's workgroups fill the slots the other's tail frees
     hipStream_t alt_stream = nullptr;
     rrtmgp::DeviceBuffer alt_scratch;
-    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr};
+    int *col_queue[2] = {nullptr, nullptr};   // per lane: {next column, workgroups done} (queue_ensure)
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[3] = {nullptr, nullptr, nullptr};
     // small host-array solves: every array travels through ONE page-locked bounce buffer (a host memcpy per array, one
     // DMA each way) instead of one DMA per array (~15 us each, 17 arrays per solve)
     char *bounce_h = nullptr, *bounce_d = nullptr;
@@ -203,8 +204,13 @@ int stage_ensure(rrtmgp_workspace *ws, int slot, size_t bytes);
 struct Lane {
     hipStream_t stream;
     DeviceBuffer *scratch;
+    int idx;   // 0 = main, 1 = second: which column-queue counters (rrtmgp_workspace::col_queue) its launches use
 };
 int scratch_ensure(rrtmgp_workspace *ws, size_t bytes, const Lane *lane = nullptr);
+// The column queue of a lane's launches: {next column, workgroups done}, 256 bytes of device memory allocated and zeroed ONCE.
+// The kernels leave it zeroed themselves (queue_release, device.h: the last workgroup out resets both counters), so a launch
+// needs no memset in front of it (round 5: two fill kernels + their dependencies were ~15 us of a 250 us step of 512 columns).
+int queue_ensure(rrtmgp_workspace *ws, int lane_idx, int **out);
 
 // every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
 hipError_t rr_malloc(void **p, size_t bytes);

@@ -1267,6 +1267,24 @@ __device__ __forceinline__ int next_column(const ColShared<FT, CHK> &sh, const C
     return sh.misc[d.nwaves + 3];
 }
 
+// Called by every workgroup when it has left the column loop: the LAST one out zeroes {next column, workgroups done}, so the
+// counters are ready for the next launch on this lane and no memset has to be queued in front of it.  (Every workgroup has made
+// its final atomicAdd on queue[0] before it counts itself done, so the reset cannot race with a taker.)
+// NO fence: both counters are only ever touched by device-scope atomics (performed at the L2) and by the two stores of the
+// last workgroup, which the end of the kernel publishes; the same thread's last atomicAdd on queue[0] has RETURNED (its value
+// was consumed by next_column) before this one is issued.  A __threadfence() here is an L1 invalidate on gfx950: with one
+// column per workgroup (short steps) every workgroup that finished emptied the vector L1 of its CU under the three other
+// resident workgroups — +12 % on a 1 024-column step (profiles/r05_small_step_ab.txt).
+__device__ __forceinline__ void queue_release(int *queue) {
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&queue[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            __hip_atomic_store(&queue[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&queue[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
 // recurrences are carried next to the all-sky ones) ----------------------------------------
 constexpr int SWEEP_LANES = 256;  // lanes per scratch row, whatever the workgroup size (<= 256 g-points per lookup)

@@ -82,7 +82,7 @@ struct LwArgs {
     const FT *inc_flux;  // (inc_ld, ngpt) or nullptr: column col of g-point g at col + inc_ld * g
     int inc_ld;
     FT *scratch;
-    int *queue;  // next column of the persistent grid (device counter, zeroed before the launch)
+    int *queue;  // {next column of the persistent grid, workgroups done}: device counters, zero between launches (queue_release)
     ColDims dims;
     int n_angles;
     FT Ds[4], wts[4];
@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
         }
     }
+    queue_release(a.queue);
 }
 
 // fact of rte_lw_noscat_one_angle! (longwave_noscat.jl:178-180): (1 - t) / tau - t, or its series below tau_thresh.
@@ -622,6 +623,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);
         }
     }
+    queue_release(a.queue);
 }
 
 // Gauss-Jacobi-5 secants and weights, src/optics/AngularDiscretizations.jl:41-56
@@ -736,11 +738,11 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     if (grid < 0) return grid;
     const size_t sweep_bytes = (size_t)grid * d.nlev * (!twostream ? (a.n_angles == 1 ? 2 : 3) : diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
-    int rc = scratch_ensure(ws, sweep_bytes + 256);
+    int rc = scratch_ensure(ws, sweep_bytes);
     if (rc) return rc;
     a.scratch = (FT *)ws->scratch.ptr;
-    a.queue = (int *)((char *)ws->scratch.ptr + sweep_bytes);
-    RR_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), ws->stream));
+    rc = queue_ensure(ws, 0, &a.queue);   // {next column, workgroups done}: zero between launches (queue_release)
+    if (rc) return rc;
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ws->stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ws->stream, a);
     RR_HIP(hipGetLastError());

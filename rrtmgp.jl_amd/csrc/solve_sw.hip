@@ -73,7 +73,7 @@ struct SwArgs {
     DevFlux<FT> fl;
     const FT *cos_zenith, *toa_flux, *alb_dir, *alb_dif;
     FT *scratch;
-    int *queue;  // next column of the persistent grid (device counter, zeroed before the launch)
+    int *queue;  // {next column of the persistent grid, workgroups done}: device counters, zero between launches (queue_release)
     ColDims dims;
     uint64_t seed;
     int64_t col_offset;
@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
         }
     }
+    queue_release(a.queue);
 }
 
 int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel);
@@ -384,7 +385,7 @@ template <typename FT>
 int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const DevCld<FT> *cld, const DevAero<FT> *aero,
               const DevState<FT> &as, const FT *cos_zenith, const FT *toa_flux, const FT *alb_dir, const FT *alb_dif,
               const DevFlux<FT> &fl, uint64_t seed, int64_t col_offset, int max_int, const Lane *lane) {
-    const Lane main_lane{ws->stream, &ws->scratch};
+    const Lane main_lane{ws->stream, &ws->scratch, 0};
     const Lane &ln = lane ? *lane : main_lane;   // where this launch goes: the workspace's main lane, or the one it was handed
     SwArgs<FT> a{};
     a.lk = lk;
@@ -463,11 +464,11 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     }
     if (grid < 0) return grid;
     const size_t sweep_bytes = (size_t)grid * d.nlev * (diag ? 6 : 3) * SWEEP_LANES * sizeof(FT);
-    int rc = scratch_ensure(ws, sweep_bytes + 256, &ln);
+    int rc = scratch_ensure(ws, sweep_bytes, &ln);
     if (rc) return rc;
     a.scratch = (FT *)ln.scratch->ptr;
-    a.queue = (int *)((char *)ln.scratch->ptr + sweep_bytes);
-    RR_HIP(hipMemsetAsync(a.queue, 0, sizeof(int), ln.stream));
+    rc = queue_ensure(ws, ln.idx, &a.queue);   // {next column, workgroups done}: zero between launches (queue_release)
+    if (rc) return rc;
     // (last_kernel_ms = the workspace's LAST solver launch, whichever lane it ran on: include/rrtmgp_hip.h)
     if (ws->timed) RR_HIP(hipEventRecord(ws->ev_start, ln.stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, ln.stream, a);
