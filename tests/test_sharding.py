@@ -110,6 +110,12 @@ def test_bench_multi_process_path_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["unit"] == "columns/s" and d["steps"] == 2
     assert d["config"]["ncol_per_gpu"] == 4096
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    # the audit record of a scaling run: one entry per rank with its device ordinal, name, PCI address and pid (two ranks
+    # that shared a GPU, as here, show the SAME pci address and different pids: exactly what a reader must be able to see)
+    rd = d["rank_devices"]
+    assert [x["rank"] for x in rd] == [0, 1] and len({x["pid"] for x in rd}) == 2
+    assert all(x["name"] and len(x["pci"].split(":")) == 3 for x in rd) and rd[0]["pci"] == rd[1]["pci"]
+    assert d["ranks_seen"] == 2 and len(d["rank_ms_per_step"]) == 2
 
 
 @pytest.mark.gpu
