@@ -313,3 +313,48 @@ def test_fused_step_argument_errors(tables64):
         rte.update_fluxes(lws, rte.TwoStreamSWRTE(4, 10, np.float64, sb), as_, t["lw"], t["sw"])
     with pytest.raises(ValueError, match="params"):
         rte.update_fluxes(lws, sws, as_, t["lw"], t["sw"], prepare=GA.prepare_atmosphere_opts(as_, t["lw"]))
+
+
+@pytest.mark.gpu
+def test_lane_orders_of_a_short_step_give_the_same_bits():
+    """the two-lane form of a short fused step (LW on the main lane, SW on the second) against the one-lane form, and
+    the two alternative queueing orders kept behind RRTMGP_HIP_STEP_ORDER — with the clear-sky diagnostic, aerosols, the
+    preparation cascade and the isothermal layer in the step.  The switches are read once per process: one child each, a
+    digest of every output and of the prepared state."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import rrtmgp_jl_amd
+from rrtmgp_jl_amd import grid_adaptation as GA, solver as L2, synthetic as S
+from rrtmgp_jl_amd.states import TEST_PARAMETERS
+import test_update_fluxes as T
+t = {k: None for k in ()}
+lw, sw = S.make_gas_lookup("lw", np.float64), S.make_gas_lookup("sw", np.float64)
+tabs = dict(lw=lw, sw=sw, cld_lw=S.make_cloud_lookup("lw", lw.n_bnd), cld_sw=S.make_cloud_lookup("sw", sw.n_bnd),
+            aero_lw=S.make_aerosol_lookup("lw", lw.bnd_lims_wn), aero_sw=S.make_aerosol_lookup("sw", sw.bnd_lims_wn))
+h = hashlib.sha256()
+for method, ncol in (("diag", 300), ("allsky", 37)):
+    fused, _ = T._pair(tabs, np.float64, method, True, ncol=ncol, nlay=20, iso=True, interpolation=GA.UniformZ)
+    for seed in (3, 4):
+        L2.update_fluxes(fused, seed)
+    for g in T.GETTERS + (T.CLEAR_GETTERS if method == "diag" else ()):
+        h.update(np.ascontiguousarray(getattr(L2, g)(fused)).tobytes())
+    for a in T._state_arrays(fused.as_).values():
+        h.update(np.ascontiguousarray(a).tobytes())
+    h.update(np.ascontiguousarray(L2.sw_cloud_cover(fused)).tobytes())
+print("DIGEST", h.hexdigest())
+''' % (root, os.path.join(root, "tests"))
+    digests = {}
+    for name, env in (("one lane", {"RRTMGP_HIP_STEP_OVERLAP": "0"}), ("two lanes", {"RRTMGP_HIP_STEP_OVERLAP": "1"}),
+                      ("order 1", {"RRTMGP_HIP_STEP_OVERLAP": "1", "RRTMGP_HIP_STEP_ORDER": "1"}),
+                      ("order 2", {"RRTMGP_HIP_STEP_OVERLAP": "1", "RRTMGP_HIP_STEP_ORDER": "2"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        digests[name] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
+    _ = hashlib
