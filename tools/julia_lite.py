@@ -424,7 +424,7 @@ BASE = {"ccall", "Ref", "Ptr", "Cvoid", "Cint", "Csize_t", "Int32", "Int64", "UI
         "Number", "Function", "stride", "strides", "StridedMatrix", "StridedArray", "Module", "isdefined", "filter!", "in",
         # round 5 (HIPArray): array-type plumbing
         "prod", "UndefInitializer", "Dims", "throw", "DimensionMismatch", "iszero", "reinterpret", "fill", "fill!", "SubArray",
-        "DenseArray", "Vararg", "map", "similar", "copy", "CartesianIndices"}
+        "DenseArray", "Vararg", "map", "similar", "copy", "CartesianIndices", "IO", "MIME", "print", "show", "summary"}
 
 
 def _locals_of(m: Method) -> set:
