@@ -452,7 +452,8 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
             const size_t lds4 = carve_shared(dummy_half, (char *)nullptr, d);
             const int cap3 = column_grid(ws, INT_MAX, threads, lds, (const void *)kern);
             const int cap4 = lds4 <= 160 * 1024 ? column_grid(ws, INT_MAX, threads, lds4, (const void *)k4) : -1;
-            if (cap4 > cap3 && as.ncol > cap3 && (d.nlay <= 64 || cap3 <= 2 * ws->n_cu)) {
+            static const bool force_half = getenv("RRTMGP_HIP_FORCE_DIAG_HALF") != nullptr;  // A/B switch: whenever they admit one more
+            if (cap4 > cap3 && as.ncol > cap3 && (force_half || d.nlay <= 64 || cap3 <= 2 * ws->n_cu)) {
                 kern = k4; lds = lds4; grid = std::min(as.ncol, cap4);
             }
         } else if (diag && !no_diag_half) {   // the 16-layer records do not fit the LDS at all: the 8-layer ones may
