@@ -453,7 +453,11 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
             const int cap3 = column_grid(ws, INT_MAX, threads, lds, (const void *)kern);
             const int cap4 = lds4 <= 160 * 1024 ? column_grid(ws, INT_MAX, threads, lds4, (const void *)k4) : -1;
             static const bool force_half = getenv("RRTMGP_HIP_FORCE_DIAG_HALF") != nullptr;  // A/B switch: whenever they admit one more
-            if (cap4 > cap3 && as.ncol > cap3 && (force_half || d.nlay <= 64 || cap3 <= 2 * ws->n_cu)) {
+            // Round 5 swept the rule at 60 / 64 / 72 / 73 / 80 layers with and without MERRA aerosols (tools/experiments/
+            // diag_rule_sweep.sh, profiles/r05_diag_rule_sweep_ab.txt): without aerosols it stands (65-80 layers: the fourth
+            // workgroup costs 0.3-1.6 percent); WITH aerosols this kernel gains from it up to 80 layers
+            // (SW 15.56 -> 14.55 ms at 72 layers, 17.49 -> 16.55 at 80; LW 11.65 -> 11.52 at 72, but 12.83 -> 13.07 at 80).
+            if (cap4 > cap3 && as.ncol > cap3 && (force_half || d.nlay <= 64 || cap3 <= 2 * ws->n_cu || (aero && d.nlay <= 80))) {
                 kern = k4; lds = lds4; grid = std::min(as.ncol, cap4);
             }
         } else if (diag && !no_diag_half) {   // the 16-layer records do not fit the LDS at all: the 8-layer ones may
