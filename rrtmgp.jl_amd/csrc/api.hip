@@ -1735,15 +1735,19 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
     }
     TRY(st.flush());  // packed small step: the one upload
 
-    // ---- [prepare] -> LW -> SW -> net on the workspace stream.  Two kinds of SHORT step run their SW kernels on the
-    // workspace's second lane instead (own stream, own sweep scratch; forked after the preparation, joined before the net sums):
-    //  - up to 2 columns per CU: the two grids fit the chip side by side (256 x 72 with aerosols: 0.296 -> 0.211 ms);
-    //  - a few columns per resident workgroup (BASELINE config 4's 4 096 columns are 4 each): the SW workgroups start in the
-    //    slots the LW tail frees — the last column of each workgroup finishes alone — worth 1-2 % from 4 096 to 12 288 columns.
-    // Between the two (1 024-2 048 columns: 3 % slower) and from 16 384 columns on (nothing) the step stays on one lane.
-    // tools/experiments/README.md round 4, step_overlap_ab.sh.  RRTMGP_HIP_STEP_OVERLAP=0/1 forces it off / on.
+    // ---- [prepare] -> LW -> SW -> net on the workspace stream.  SHORT steps run their SW kernels on the workspace's second lane
+    // instead (own stream, own sweep scratch; forked after the preparation, joined before the net sums).  When that pays was swept
+    // in round 5 against f = columns / resident workgroup slots (4 per CU), one lane vs two, 72 layers with aerosols and 64 layers
+    // without (tools/experiments/overlap_range_sweep.sh, profiles/r05_overlap_range_sweep.txt):
+    //   f <= 0.65       the two grids fit the chip side by side:                         -22 ... -26 % in both configurations
+    //   0.7 <= f <= 1   the second grid only gets in the first one's way:                 +6 ... +11 %
+    //   1.05 < f < 1.5  the SW workgroups start in the slots the LW tail frees:           -8 ... -11 % (aerosols), -1 ... -2 %
+    //   2.1 < f <= 6    the same, smaller:  -1 ... -4 % with aerosols (BASELINE config 4 is f = 4), +0.5 ... +2 % without
+    //   beyond          nothing either way (+-0.2 %).
+    // (Round 4's rule, from five points: f <= 0.5 or 4 <= f <= 12.)  RRTMGP_HIP_STEP_OVERLAP=0/1 forces it off / on.
     static const int force_overlap = getenv("RRTMGP_HIP_STEP_OVERLAP") ? atoi(getenv("RRTMGP_HIP_STEP_OVERLAP")) : -1;
-    const bool short_step = ncol <= 2 * (size_t)ws->n_cu || (ncol >= 16 * (size_t)ws->n_cu && ncol <= 48 * (size_t)ws->n_cu);
+    const double f_slots = (double)ncol / (4.0 * (double)ws->n_cu);
+    const bool short_step = f_slots <= 0.65 || (f_slots > 1.05 && f_slots < 1.5) || (use_aero && f_slots > 2.1 && f_slots <= 6.0);
     const bool overlap = !(chunk && !st.packed) && (force_overlap >= 0 ? force_overlap != 0 : short_step);
     if (overlap) TRY(lane_resources(ws));
     if (prep) TRY(launch_prepare<FT>(ws, pv, *a->params, *po, false));

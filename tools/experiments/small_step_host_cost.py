@@ -12,16 +12,18 @@ from rrtmgp_jl_amd import rte, synthetic as S
 ft = np.float32
 lw, sw = S.make_gas_lookup("lw", ft), S.make_gas_lookup("sw", ft)
 cl, cs = S.make_cloud_lookup("lw", lw.n_bnd, ft), S.make_cloud_lookup("sw", sw.n_bnd, ft)
-al, asw = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft), S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft)
+AER = os.environ.get("AEROSOLS", "1") == "1"
+NLAY = int(os.environ.get("NLAY", "72"))
+al, asw = (S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft), S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft)) if AER else (None, None)
 dev = torch.device("cuda", 0)
-for ncol in (512, 1024, 2048, 4096):
-    as_h, lb_h, sb_h = S.make_columns(ncol, 72, ft, seed=2026, aerosols=True, cos_zenith=0.86)
+for ncol in [int(x) for x in os.environ.get('NCOLS', '512,1024,2048,4096').split(',')]:
+    as_h, lb_h, sb_h = S.make_columns(ncol, NLAY, ft, seed=2026, aerosols=AER, cos_zenith=0.86)
     as_d, lb_d, sb_d = as_h.to_device(dev), lb_h.to_device(dev), sb_h.to_device(dev)
-    ws = rte.Workspace(ncol, 72, ft, 0)
-    lws = rte.TwoStreamLWRTE(ncol, 72, ft, lb_d, flux_device=dev, workspace=ws)
-    sws = rte.TwoStreamSWRTE(ncol, 72, ft, sb_d, flux_device=dev, workspace=ws)
-    net = torch.empty((ncol, 73), dtype=torch.float32, device=dev)
-    d = [rte.DeviceLookup(x, 0) for x in (lw, sw, cl, cs, al, asw)]
+    ws = rte.Workspace(ncol, NLAY, ft, 0)
+    lws = rte.TwoStreamLWRTE(ncol, NLAY, ft, lb_d, flux_device=dev, workspace=ws)
+    sws = rte.TwoStreamSWRTE(ncol, NLAY, ft, sb_d, flux_device=dev, workspace=ws)
+    net = torch.empty((ncol, NLAY + 1), dtype=torch.float32, device=dev)
+    d = [rte.DeviceLookup(x, 0) if x is not None else None for x in (lw, sw, cl, cs, al, asw)]
 
     def step():
         rte.update_fluxes(lws, sws, as_d, d[0], d[1], d[2], d[3], d[4], d[5], seed=1, net_flux=net)
