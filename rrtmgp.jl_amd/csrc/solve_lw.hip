@@ -679,13 +679,16 @@ int launch_lw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     ColShared<FT, chunk_layers(2)> dummy_aero;
     size_t lds = ca_aero ? carve_shared(dummy_aero, (char *)nullptr, d) : carve_shared(dummy, (char *)nullptr, d);
     // main Float32 instances: 8-layer chunks when that is what keeps 4 workgroups resident per CU (160 KB / 4).  Measured:
-    // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80
+    // 72 layers LW 21.4 -> 20.2 ms; at 96 layers 3 workgroups with 16-layer chunks are faster (28.0 vs 29.5 ms), hence <= 80 (round 2 kernels; re-measured in round 5, below)
     static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
     // Float64: the 8-layer instances are compiled for RR_F64_HALF_WAVES waves per SIMD (device.h) and taken when their
     // records let that many workgroups share the CU's LDS
     constexpr size_t lds_cap = sizeof(FT) == 4 ? 40960 : (160 * 1024) / RR_F64_HALF_WAVES;
     ColShared<FT, half_chunk_layers<FT>()> dummy_half;
-    const bool half = !no_half && (sizeof(FT) == 4 ? d.nlay <= 80 : RR_F64_HALF_WAVES > 2) && twostream && !diag && !fl.band_up && !aero &&
+    // (round 5 sweep, tools/experiments/half_rule_sweep.sh, profiles/r05_half_rule_sweep_ab.txt: 80 layers +6.9 %, 84 +6.1 %, 88 +4.5 %,
+    // 96 layers LW 11.49 -> 10.98 ms but SW 13.04 -> 13.12: the limit was 80 for both kernels since round 2; now 96 here)
+    static const bool force_half_main = getenv("RRTMGP_HIP_FORCE_HALF_CHUNKS") != nullptr;  // A/B switch: whatever the depth
+    const bool half = !no_half && (sizeof(FT) == 4 ? (d.nlay <= 96 || force_half_main) : RR_F64_HALF_WAVES > 2) && twostream && !diag && !fl.band_up && !aero &&
                       lds > lds_cap && carve_shared(dummy_half, (char *)nullptr, d) <= lds_cap;
     if (half) lds = carve_shared(dummy_half, (char *)nullptr, d);
     if (diag) {
