@@ -24,8 +24,13 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys:
   * `rank_devices`: ordinal / name / PCI address of the device every rank ran on;
   * `host_end_to_end`: the same workload handed over as HOST arrays (library stages H2D / D2H over PCIe
     every step): never `value`;
-  * `precise_f32`: the IEEE-Float32 build of the library (-DRR_PRECISE_F32, correctly rounded div / sqrt);
-  * `variants`: Float64, MERRA aerosols, one-pass clear-sky diagnostic, 1 048 576 columns on one GPU;
+  * `variants`: Float64, MERRA aerosols, one-pass clear-sky diagnostic, 1 048 576 columns on one GPU, `gcm_mix` (half the
+    columns at night, fractional cloud fractions), `fast_f32` (the opt-in raw-instruction Float32 build, `make fast`; the
+    headline library is the IEEE-accurate one: correctly rounded div / sqrt, exp <= 1.2 ulp); a leg whose kernels have a
+    committed rocprofv3 summary on the current kernel sources (profiles/latest_<leg>.json) carries a `profiled` block;
+  * `a100_shape`: the reference's own benchmark grid (86 400 columns x 63 layers, docs/src/howto/gpu.md:116-150,
+    perf/benchmark_baselines/nvidia_a100_sxm4_40gb.txt) for Float32 / Float64 x clear / all-sky / all-sky + aerosols, LW and
+    SW kernel times separately, next to the published A100 numbers (context, never `value`);
   * `cpu_baseline`: the plain-C oracle on a bounded sample of the same workload on this box's host cores.
 The extra legs run as short child processes after the timed region (rank 0, N = 1 only; `--no-legs` skips them).
 """
@@ -84,6 +89,9 @@ def parse_args(argv=None):
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--aerosols", action="store_true")
     ap.add_argument("--cld-frac", type=float, default=1.0, help="cloud fraction of cloudy layers (reference benchmark: 1)")
+    ap.add_argument("--gcm-mix", action="store_true",
+                    help="a GCM-like column mix instead of the all-day / overcast benchmark columns: half the columns at night "
+                         "(mu0 <= 0), the others with their own zenith angle, a random cloud fraction per cloudy layer")
     ap.add_argument("--cpu-sample", type=int, default=None, help="columns for the CPU baseline (0 disables)")
     ap.add_argument("--host", action="store_true",
                     help="hand HOST arrays to the C ABI (library stages H2D/D2H every step): the PCIe-inclusive rate, "
@@ -172,6 +180,68 @@ def vmem_pipeline(k):
             "instructions_4_byte": narrow, "instructions_16_byte": wide, "profiled_kernel_ms": k["avg_us"] / 1e3,
             "model": "8 cycles per 4-byte, 16.5 per 8..16-byte wave instruction (tools/ubench/gather_l1.hip); "
                      "counters SQ_INSTS_VMEM_RD/WR, GRBM_GUI_ACTIVE of the profile named in roofline.traffic_source"}
+
+
+def leg_profile(leg, ncol, nlay, ngpt_lw, ngpt_sw, peak, lw_cell):
+    """`profiled` block of a variant leg: the same flops-per-cell pricing as `roofline.profiled`, on the rocprofv3
+    --kernel-trace --stats averages committed as profiles/latest_<leg>.json (tools/profile2.sh with BENCH_ARGS = the leg's
+    flags) — only when that summary was taken on the kernel sources being timed."""
+    path = os.path.join(ROOT, "profiles", f"latest_{leg}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        pj = json.load(fh)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocprof_summary import kernel_source_sha256
+    if pj.get("kernel_source_sha256") != kernel_source_sha256(ROOT):
+        return {"source": pj.get("source"), "note": "profile was taken on other kernel sources: withheld"}
+    out = {"source": f"rocprofv3 --kernel-trace --stats averages of profiles/latest_{leg}.json ({pj.get('source')})",
+           "git_sha": pj.get("git_sha"), "kernels": {}}
+    tot_ms = tot_flops = 0.0
+    for name, k in pj.get("kernels", {}).items():
+        if not k.get("avg_us"):
+            continue
+        r = kernel_valu(name, k["avg_us"] / 1e3, ncol, nlay, ngpt_lw if name.startswith("lw") else ngpt_sw, peak, lw_cell)
+        if k.get("FETCH_SIZE") is not None and k.get("WRITE_SIZE") is not None:
+            r["traffic"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        out["kernels"][name] = r
+        tot_ms += r["kernel_ms"]
+        tot_flops += r["achieved"] * r["kernel_ms"]
+    if tot_ms > 0:
+        out["step"] = {"kernel_ms": tot_ms, "achieved": tot_flops / tot_ms, "frac": tot_flops / tot_ms / peak, "peak": peak}
+    return out
+
+
+# The reference's published numbers for its own benchmark grid, 86 400 columns x 63 layers (ns, minimum;
+# /root/reference/perf/benchmark_baselines/nvidia_a100_sxm4_40gb.txt:6-17) and the wall times of docs/src/howto/gpu.md:138-150
+A100_MIN_NS = {("all_sky", "f32"): (7.26150458e8, 6.71148384e8), ("all_sky", "f64"): (9.92342112e8, 9.40083761e8),
+               ("all_sky_with_aerosols", "f32"): (7.97787842e8, 7.28343007e8), ("all_sky_with_aerosols", "f64"): (1.09698575e9, 9.66275699e8),
+               ("clear_sky", "f32"): (4.89919056e8, 4.55409919e8), ("clear_sky", "f64"): (6.82068605e8, 6.39967283e8)}
+A100_DOC_S = {("clear_sky", "f32"): 0.95, ("all_sky", "f32"): 1.40, ("all_sky_with_aerosols", "f32"): 1.56,
+              ("clear_sky", "f64"): 1.30, ("all_sky", "f64"): 1.92, ("all_sky_with_aerosols", "f64"): 2.07}
+
+
+def a100_shape_legs():
+    """Same-shape context for the reference's published tables: every cell of docs/src/howto/gpu.md:138-150 and of the A100
+    ratchet file on the reference's own grid (86 400 x 63, two-stream LW + SW), LW and SW kernel times separately."""
+    cells = {}
+    for case, flags in (("clear_sky", ["--no-clouds"]), ("all_sky", []), ("all_sky_with_aerosols", ["--aerosols"])):
+        for dt in ("f32", "f64"):
+            leg = run_leg(f"a100_shape_{case}_{dt}", ["--ncol", "86400", "--nlay", "63", "--dtype", dt] + flags)
+            if "error" not in leg:
+                lw_ns, sw_ns = A100_MIN_NS[(case, dt)]
+                step_s = leg["min_ms"] * 1e-3 if "min_ms" in leg else leg["ms_per_step"] * 1e-3
+                leg = {"lw_kernel_ms": leg["lw_kernel_ms"], "sw_kernel_ms": leg["sw_kernel_ms"], "step_min_ms": leg.get("min_ms"),
+                       "step_median_ms": leg.get("median_ms"), "columns_per_s": leg["value"],
+                       "a100_lw_ms": lw_ns / 1e6, "a100_sw_ms": sw_ns / 1e6, "a100_doc_step_s": A100_DOC_S[(case, dt)],
+                       "lw_vs_a100": lw_ns / 1e6 / leg["lw_kernel_ms"], "sw_vs_a100": sw_ns / 1e6 / leg["sw_kernel_ms"],
+                       "step_vs_a100_ratchet_min": (lw_ns + sw_ns) / 1e9 / step_s, "step_vs_a100_doc": A100_DOC_S[(case, dt)] / step_s}
+            cells[f"{case}_{dt}"] = leg
+    return {"grid": "86 400 columns x 63 layers, 256 + 224 g-points, two-stream LW + SW (perf/benchmark_ratchet.jl:49-50)",
+            "cells": cells,
+            "note": "context only, never `value`: synthetic tables and columns of the reference's dimensions on ONE MI355X next to the "
+                    "reference's published A100-SXM4-40GB minimum times (benchmark_baselines/nvidia_a100_sxm4_40gb.txt) and "
+                    "documented wall times (docs/src/howto/gpu.md:138-150); *_vs_a100 = A100 time / MI355X time"}
 
 
 def run_l2(args):
@@ -274,8 +344,9 @@ def main():
     al = S.make_aerosol_lookup("lw", lw.bnd_lims_wn, ft) if args.aerosols else None
     asw = S.make_aerosol_lookup("sw", sw.bnd_lims_wn, ft) if args.aerosols else None
     col_offset = c_lo if strong else rank * ncol
+    mix = dict(cos_zenith=None, night_fraction=0.5, random_cld_frac=True) if args.gcm_mix else dict(cos_zenith=0.86)
     as_h, lb_h, sb_h = S.make_columns(ncol0, nlay, ft, seed=2026, col_offset=col_offset, clouds=clouds,
-                                      cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
+                                      cld_frac=args.cld_frac, aerosols=args.aerosols, **mix)
     shards = None
     if args.host:
         if args.tile != 1:
@@ -436,6 +507,12 @@ def main():
             if step_ms:
                 rec["min_ms"], rec["median_ms"] = step_ms["min"], step_ms["median"]
                 rec["value_at_min"] = ncol / (step_ms["min"] * 1e-3)
+            if args.gcm_mix:
+                rec["workload"] = (f"all-sky LW+SW two-stream, {ncol} x {nlay}: {float((sb_h.cos_zenith <= 0).mean()):.2f} of the columns "
+                                   "at night, per-column zenith angle, random cloud fraction per cloudy layer")
+            prof_leg = leg_profile(args.leg, ncol, nlay, lw.n_gpt, sw.n_gpt, valu_peak, lw_cell)
+            if prof_leg:
+                rec["profiled"] = prof_leg
             print(json.dumps(rec))
             return
         ms_lw, ms_sw = k_lw, k_sw
@@ -459,7 +536,7 @@ def main():
         prof = os.path.join(ROOT, "profiles", "latest.json")
         default_workload = (not args.aerosols and ncol == NCOL_PER_GPU and nlay == NLAY and args.dtype == "f32"
                             and not args.host and args.clear_sky_diag == "off" and not noscat and clouds and not args.lw_only
-                            and not strong)
+                            and not strong and not args.gcm_mix)
         vmem = None
         if os.path.exists(prof) and default_workload:
             # HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
@@ -551,10 +628,15 @@ def main():
             # reference's device array type buys — nothing crosses PCIe inside update_fluxes!
             out["l2_update_fluxes_device"] = run_leg("l2_device", ["--l2", "fused", "--resident"])
             out["l2_update_fluxes_device"]["vs_value"] = (out["l2_update_fluxes_device"].get("value", 0.0) / value) if value else None
-            precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
-            out["precise_f32"] = (run_leg("precise_f32", [], env={"RRTMGP_HIP_LIBRARY": precise}) if os.path.exists(precise)
-                                  else {"error": "libhip_rrtmgp_precise.so not built (make -C rrtmgp.jl_amd/csrc precise)"})
+            fast = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_fast.so")
             out["variants"] = {
+                # the opt-in raw-instruction Float32 build (-DRR_FAST_F32: __expf, v_rcp_f32, v_sqrt_f32 as they come); `value`
+                # above is the shipped library, whose Float32 forms are IEEE-accurate (rrtmgp_hip_build_flags() == "")
+                "fast_f32": (run_leg("fast_f32", [], env={"RRTMGP_HIP_LIBRARY": fast}) if os.path.exists(fast)
+                             else {"error": "libhip_rrtmgp_fast.so not built (make -C rrtmgp.jl_amd/csrc fast)"}),
+                # the headline's columns are all sunlit and overcast where cloudy (the reference benchmark's choice); a GCM's
+                # are not: half of them at night (the SW solve is skipped there), partial cloud fractions (McICA draws)
+                "gcm_mix": run_leg("gcm_mix", ["--gcm-mix"]),
                 "f64": run_leg("f64", ["--dtype", "f64"]),
                 "aerosols": run_leg("aerosols", ["--aerosols"]),
                 "clear_sky_diag": run_leg("clear_sky_diag", ["--clear-sky-diag", "one-pass"]),
@@ -573,6 +655,7 @@ def main():
                 "config4_fused_step_device": run_leg("config4_fused_step_device", ["--ncol", "4096", "--nlay", "72", "--aerosols",
                                                                                    "--fused-step", "--steps", "50", "--warmup", "5"]),
             }
+            out["a100_shape"] = a100_shape_legs()
             # BASELINE config 4 is a STRONG-scaling case: 4096 columns over 1 -> 8 GPUs, i.e. 4096 / 2048 / 1024 / 512 columns
             # per GPU.  The driver measures the curve when it has an 8-GPU node; this is its one-GPU prediction: the shard each
             # rank would own, solved alone on this GPU (columns are independent and there is no collective, so N ranks take
@@ -606,7 +689,7 @@ def main():
 
             def cpu_run(n):
                 cas, clb, csb = S.make_columns(n, nlay, ft, seed=2026, col_offset=0, clouds=clouds,
-                                               cld_frac=args.cld_frac, aerosols=args.aerosols, cos_zenith=0.86)
+                                               cld_frac=args.cld_frac, aerosols=args.aerosols, **mix)
                 tc = time.perf_counter()
                 O.solve_lw(cas, clb, lw, cl, al, seed=2026)
                 O.solve_sw(cas, csb, sw, cs, asw, seed=2026)

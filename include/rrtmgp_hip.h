@@ -619,8 +619,8 @@ int rrtmgp_hip_eval_primitive(int device, int32_t op, int32_t ftype, const void 
 int rrtmgp_hip_last_error(char *buf, size_t n);
 /* "major.minor.patch", followed by " [flags]" when the library was not built as shipped */
 const char *rrtmgp_hip_version(void);
-/* The compile-time switches this library was built with, space separated: "" for the shipped build, "RR_PRECISE_F32"
- * for the IEEE-Float32 build; anything else (RR_EXP_*, tuning values) marks an experimental build whose results may be
+/* The compile-time switches this library was built with, space separated: "" for the shipped build (IEEE-accurate
+ * Float32 forms), "RR_FAST_F32" for the raw-instruction Float32 build (`make fast`); anything else (RR_EXP_*, tuning values) marks an experimental build whose results may be
  * wrong by construction (rrtmgp.jl_amd/csrc/variants.h). */
 const char *rrtmgp_hip_build_flags(void);
 /* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,

@@ -9,8 +9,8 @@ import subprocess
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RRTMGP_HIP_LIBRARY selects another build of the same library (the IEEE-Float32 build
-# `libhip_rrtmgp_precise.so`, or an A/B variant under variants/); the default is the shipped one.
+# RRTMGP_HIP_LIBRARY selects another build of the same library (the raw-instruction Float32 build
+# `libhip_rrtmgp_fast.so`, or an A/B variant under variants/); the default is the shipped one.
 SO_PATH = os.environ.get("RRTMGP_HIP_LIBRARY") or os.path.join(_HERE, "libhip_rrtmgp.so")
 CSRC = os.path.join(_HERE, "csrc")
 
@@ -95,7 +95,7 @@ def build(force: bool = False) -> str:
     """Compile libhip_rrtmgp.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
-    for target in ([], ["precise"]):   # the shipped library, then the IEEE-Float32 build bench.py times next to it
+    for target in ([], ["fast"]):   # the shipped library (IEEE-accurate Float32), then the fast-forms build bench.py times next to it
         r = subprocess.run(["make", "-C", CSRC, "-j4"] + target, capture_output=True, text=True)
         if r.returncode != 0:
             raise RRTMGPHipError("building libhip_rrtmgp.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])

@@ -2470,7 +2470,7 @@ const char *rrtmgp_hip_build_flags(void) {
     return s.c_str();
 }
 const char *rrtmgp_hip_version(void) {
-    static const std::string s = std::string("0.4.0") + (*rrtmgp_hip_build_flags() ? std::string(" [") + rrtmgp_hip_build_flags() + "]" : std::string());
+    static const std::string s = std::string("0.5.0") + (*rrtmgp_hip_build_flags() ? std::string(" [") + rrtmgp_hip_build_flags() + "]" : std::string());
     return s.c_str();
 }
 

@@ -48,13 +48,16 @@ template <> struct Num<double> {
     static __device__ __forceinline__ double pi() { return 3.14159265358979323846; }
 };
 
-// Float32 device math.  By default exp is v_exp_f32 based (__expf, ~2 ulp), divisions and
-// square roots are the 2.5-ulp forms (Makefile: -fno-hip-fp32-correctly-rounded-divide-sqrt) and
-// 1 - e^{-x} is evaluated by exp_pair below (<= 1.6 ulp).  Measured against the Float64 oracle
-// the broadband fluxes are as accurate as with the correctly rounded forms ("Float32
-// numerics"); build with -DRR_PRECISE_F32 (and without the flag) to get the latter.  Float64 uses
-// libm and IEEE division throughout, except exp_pair below (one argument reduction for both results).
-#ifdef RR_PRECISE_F32
+// Float32 device math.  The library computes with IEEE-accurate forms by default (hard part 5: the
+// reference runs Julia's exp (< 1 ulp) and IEEE `/` and sqrt, docs/src/precision.md): correctly rounded quotients,
+// reciprocals and square roots, e^-x to 1.2 ulp, all written out below around v_rcp_f32 / v_rsq_f32 / v_exp_f32 with FMA
+// residual steps (no libm call and no compiler-expanded division in the g-point loops); tests/test_primitives.py measures
+// every form on the GPU against Float64.  -DRR_FAST_F32 (`make fast` -> libhip_rrtmgp_fast.so, with
+// -fno-hip-fp32-correctly-rounded-divide-sqrt) builds the raw-instruction forms instead (__expf, v_rcp_f32, v_sqrt_f32:
+// 1-14 ulp), an opt-in that bench.py reports as variants.fast_f32.
+// Float64 uses hand-written forms of <= 2 ulp (exp_pair, m_rcp, m_div below) in both builds; -DRR_LIBM_F64 (an
+// experiment) swaps libm and the compiler's division back in.
+#ifndef RR_FAST_F32
 __device__ __forceinline__ float m_exp(float x) { return expf(x); }
 #else
 __device__ __forceinline__ float m_exp(float x) { return __expf(x); }
@@ -74,12 +77,12 @@ __device__ __forceinline__ float m_cos(float x) { return cosf(x); }
 __device__ __forceinline__ double m_cos(double x) { return cos(x); }
 // Division and reciprocal of well-scaled Float32 quantities in the per-g-point loops (optical
 // depths, albedos, two-stream denominators: never denormal or near overflow): v_rcp_f32 (1 ulp)
-// times the numerator.  Float64, and -DRR_PRECISE_F32, use the IEEE division.
+// times the numerator (the -DRR_FAST_F32 forms; the default forms add one FMA residual step, below).
 // Float64: v_rcp_f64 refined by two Newton steps (5 instructions), and for a quotient one residual correction on top
 // (8 instructions; the compiler's IEEE expansion with its scaling and fix-up steps is 13): at most 1 ulp for the well-scaled
 // operands of the g-point loops, far inside the Float64 parity budget (1e-11 relative).  A zero divisor gives NaN / inf
 // exactly where `1.0 / x` gives inf, and every such call site selects its result away (tau <= 0).
-#ifdef RR_PRECISE_F32
+#ifdef RR_LIBM_F64
 __device__ __forceinline__ double m_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ double m_div(double a, double b) { return a / b; }
 #else
@@ -94,7 +97,7 @@ __device__ __forceinline__ double m_div(double a, double b) {
     return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 }
 #endif
-#ifdef RR_PRECISE_F32
+#ifndef RR_FAST_F32
 // IEEE-accurate Float32 forms of the per-g-point loops, written out (round 5) instead of `/`, sqrtf and libm: the compiler's
 // correctly rounded division is 10 instructions between two s_setreg (denormal mode on and off again), sqrtf likewise, and
 // libm's expf / expm1f are ~15 / ~45.  The operands here are well scaled (optical depths, albedos, two-stream denominators:
@@ -142,7 +145,7 @@ template <typename FT> __device__ __forceinline__ FT m_abs(FT a) { return a < FT
 // together; this is ~25).  x = n ln2 + r with |r| <= ln2 / 2, p = expm1(-r) by a degree-13 polynomial (next term
 // 0.347^14 / 14! = 4e-18), e^-x = 2^-n (1 + p); 1 - e^-x is -p itself when n = 0 (no cancellation for small x, which is
 // what expm1 is for) and 1 - e^-x otherwise (e^-x <= 0.71 there).  Error <= 2 ulp on both results for x >= 0; x beyond
-// ~745 gives exactly (0, 1) like libm.  RR_PRECISE_F32 builds keep libm.
+// ~745 gives exactly (0, 1) like libm.  -DRR_LIBM_F64 builds keep libm.
 // (1 - e^-r) for |r| <= ln2 / 2, and the reduction x = n ln2 + r of a non-negative x
 __device__ __forceinline__ double exp_reduce(double x, int &ni) {
     // an overflowed optical depth (+inf, or beyond 2^52 ln 2 where the reduction loses r) must saturate to an opaque layer,
@@ -170,7 +173,7 @@ __device__ __forceinline__ double exp_reduce(double x, int &ni) {
     return r * q;                                                  // (may be slightly negative: r in [-ln2/2, ln2/2])
 }
 __device__ __forceinline__ void exp_pair(double x, double &e1, double &om1) {
-#ifdef RR_PRECISE_F32
+#ifdef RR_LIBM_F64
     e1 = exp(-x);
     om1 = -expm1(-x);
 #else
@@ -182,7 +185,7 @@ __device__ __forceinline__ void exp_pair(double x, double &e1, double &om1) {
 }
 // e^-y for y >= 0 (transmissivities, the direct beam): the same reduction in Float64, the fast / libm exp in Float32
 __device__ __forceinline__ double m_exp_neg(double y) {
-#ifdef RR_PRECISE_F32
+#ifdef RR_LIBM_F64
     return exp(-y);
 #else
     int ni;
@@ -204,13 +207,13 @@ __device__ __forceinline__ float exp_neg_acc(float y) {
     const float e = __builtin_amdgcn_exp2f(p);
     return fmaf(e, pl * 0.6931471824645996f, e);
 }
-#ifdef RR_PRECISE_F32
+#ifndef RR_FAST_F32
 __device__ __forceinline__ float m_exp_neg(float y) { return exp_neg_acc(y); }
 #else
 __device__ __forceinline__ float m_exp_neg(float y) { return m_exp(-y); }
 #endif
 __device__ __forceinline__ void exp_pair(float x, float &e1, float &om1) {
-#ifdef RR_PRECISE_F32
+#ifndef RR_FAST_F32
     e1 = exp_neg_acc(x);
 #else
     e1 = __expf(-x);

@@ -1,7 +1,8 @@
 // variants.h — every compile-time switch of the kernels, in one place.
 //
-// The shipped library is built with none of them (Makefile: `make`), the IEEE-Float32 build with RR_PRECISE_F32 alone
-// (`make precise`).  What is left besides that are TUNABLES with a shipped default.  A build with another value is an
+// The shipped library is built with none of them (Makefile: `make`): IEEE-accurate Float32 forms, device.h.  The
+// raw-instruction Float32 build takes RR_FAST_F32 alone (`make fast` -> libhip_rrtmgp_fast.so); RR_LIBM_F64 (experiment)
+// puts libm and the compiler's division back under the Float64 forms.  What is left besides that are TUNABLES with a shipped default.  A build with another value is an
 // experiment: it compiles only with -DRR_EXPERIMENTS (`make variant` adds it) and the library says what it was built with
 // (rrtmgp_hip_build_flags, also appended to rrtmgp_hip_version), so an experimental .so cannot pass for the shipped one:
 // tests/test_abi.py asserts that the shipped library reports no flags.
@@ -33,9 +34,18 @@
 #define RR_STR2(x) #x
 #define RR_STR(x) RR_STR2(x)
 #ifdef RR_PRECISE_F32
-#define RR_BUILD_FLAGS_PRECISE " RR_PRECISE_F32"
+#error "RR_PRECISE_F32 is gone: the IEEE-accurate Float32 forms are the default build since round 6 (the opt-in is RR_FAST_F32)"
+#endif
+#ifdef RR_FAST_F32
+#define RR_BUILD_FLAGS_PRECISE " RR_FAST_F32"
 #else
 #define RR_BUILD_FLAGS_PRECISE ""
+#endif
+#ifdef RR_LIBM_F64
+#define RR_HAS_RR_LIBM_F64 " RR_LIBM_F64"
+#define RR_ANY_EXPERIMENT 1
+#else
+#define RR_HAS_RR_LIBM_F64 ""
 #endif
 #if RR_MIN_WAVES != 4
 #define RR_HAS_RR_MIN_WAVES " RR_MIN_WAVES=" RR_STR(RR_MIN_WAVES)
@@ -73,7 +83,7 @@
 #else
 #define RR_HAS_RR_SWEEP_NT ""
 #endif
-#define RR_BUILD_FLAGS (RR_HAS_RR_SWEEP_NT RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK)
+#define RR_BUILD_FLAGS (RR_HAS_RR_SWEEP_NT RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK RR_HAS_RR_LIBM_F64)
 #if defined(RR_ANY_EXPERIMENT) && !defined(RR_EXPERIMENTS)
 #error "non-default tuning values are experiments: build them with `make variant NAME=... EXTRA=...` (adds -DRR_EXPERIMENTS), never into the shipped library"
 #endif

@@ -31,22 +31,34 @@ def test_struct_mirror_matches_compiled_sizes():
     for i, st in enumerate(_lib.ABI_STRUCTS):
         assert L.rrtmgp_hip_abi_sizeof(i) == C.sizeof(st), st.__name__
     assert L.rrtmgp_hip_abi_sizeof(99) == -1
-    assert L.rrtmgp_hip_version() == b"0.4.0"       # no " [flags]" suffix: built as shipped
+    assert L.rrtmgp_hip_version() == b"0.5.0"       # no " [flags]" suffix: built as shipped
 
 
 def test_shipped_library_is_built_without_experiment_switches():
-    """Every library says what it was built with: the shipped one must say nothing, the IEEE-Float32 build RR_PRECISE_F32
-    alone.  The kernel sources carry no experiment switch at all (the timing-only RR_EXP_* code of rounds 1-3 lives in
+    """Every library says what it was built with: the shipped one (IEEE-accurate Float32 forms since round 6) must say nothing, the
+    raw-instruction Float32 build RR_FAST_F32 alone.  The kernel sources carry no experiment switch at all (the timing-only RR_EXP_* code of rounds 1-3 lives in
     tools/experiments/timing_switches_r01_r03.patch); what csrc/variants.h still knows are tunables with a shipped default,
     and a build with another value compiles only with -DRR_EXPERIMENTS (`make variant`) and reports itself."""
     import subprocess
     csrc = os.path.join(ROOT, "rrtmgp.jl_amd", "csrc")
     assert _lib.lib().rrtmgp_hip_build_flags() == b""
-    precise = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
-    P = C.CDLL(precise)
+    fast = os.path.join(ROOT, "rrtmgp.jl_amd", "libhip_rrtmgp_fast.so")
+    P = C.CDLL(fast)
     P.rrtmgp_hip_build_flags.restype = C.c_char_p
     P.rrtmgp_hip_version.restype = C.c_char_p
-    assert P.rrtmgp_hip_build_flags() == b"RR_PRECISE_F32" and P.rrtmgp_hip_version() == b"0.4.0 [RR_PRECISE_F32]"
+    assert P.rrtmgp_hip_build_flags() == b"RR_FAST_F32" and P.rrtmgp_hip_version() == b"0.5.0 [RR_FAST_F32]"
+    # SURVEY section 7, hard part 5: no fast-math in the shipped library.  Its Makefile flags carry no fast-math switch,
+    # its sources reach __expf / the raw reciprocal only under RR_FAST_F32, and its code object has no __expf expansion
+    # left to find: the only v_exp_f32 sit behind the two-word argument product of exp_neg_acc (checked in
+    # tests/test_primitives.py on the GPU: <= 1.2 ulp).
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert re.search(r"^CXXFLAGS \?= \$\(BASEFLAGS\)\s*$", mk, re.M), "the default flags must not carry FASTF32"
+    assert "-ffast-math" not in mk and "-Ofast" not in mk
+    dev = open(os.path.join(csrc, "device.h")).read()
+    for m in re.finditer(r"__expf\(", dev):   # every use sits in an RR_FAST_F32 branch
+        before = dev[:m.start()]
+        last_if = max(before.rfind("#ifndef RR_FAST_F32"), before.rfind("#ifdef RR_FAST_F32"))
+        assert last_if >= 0 and before.rfind("#else", last_if) > last_if or before.rfind("#ifdef RR_FAST_F32") == last_if, dev[m.start() - 80:m.start() + 20]
     variants = open(os.path.join(csrc, "variants.h")).read()
     used, tunables = set(), set()
     for f in os.listdir(csrc):

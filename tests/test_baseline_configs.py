@@ -212,20 +212,20 @@ def test_config4_gcm_scale_shard_of_1m_columns(tables32):
     assert _maxdiff(f3, refs, SWN) < 2e-2
 
 
-def test_ieee_float32_build_passes_the_same_cases():
-    """`libhip_rrtmgp_precise.so` (-DRR_PRECISE_F32: IEEE exp / division / sqrt in Float32; bench.py times it as
-    `precise_f32`) is held to the same budgets as the shipped library: this file's BASELINE config 1-5 cases, in a child
-    process that loads it through RRTMGP_HIP_LIBRARY."""
+def test_fast_float32_build_passes_the_same_cases():
+    """`libhip_rrtmgp_fast.so` (-DRR_FAST_F32: raw v_rcp / v_sqrt / __expf forms in Float32, `make fast`; bench.py times it as
+    `variants.fast_f32`) is held to the same budgets as the shipped (IEEE-accurate) library: this file's BASELINE config 1-5
+    cases, in a child process that loads it through RRTMGP_HIP_LIBRARY."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    lib = os.path.join(root, "rrtmgp.jl_amd", "libhip_rrtmgp_precise.so")
-    assert os.path.exists(lib), "make -C rrtmgp.jl_amd/csrc precise"
+    lib = os.path.join(root, "rrtmgp.jl_amd", "libhip_rrtmgp_fast.so")
+    assert os.path.exists(lib), "make -C rrtmgp.jl_amd/csrc fast"
     env = dict(os.environ, RRTMGP_HIP_LIBRARY=lib)
     code = ("import sys, pytest; from rrtmgp_jl_amd import _lib; "
-            "assert _lib.lib().rrtmgp_hip_build_flags() == b'RR_PRECISE_F32'; "
-            "sys.exit(pytest.main([%r, '-q', '-x', '-m', 'gpu', '-k', 'not ieee_float32_build', '-p', 'no:cacheprovider']))"
+            "assert _lib.lib().rrtmgp_hip_build_flags() == b'RR_FAST_F32'; "
+            "sys.exit(pytest.main([%r, '-q', '-x', '-m', 'gpu', '-k', 'not fast_float32_build', '-p', 'no:cacheprovider']))"
             % os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -49,7 +49,7 @@ def hip_sw(as_, bcs, sw, cld=None, aero=None, twostream=True, **kw):
 
 def test_library_loads_and_sees_gpu():
     assert _lib.require_gpu() >= 1
-    assert _lib.lib().rrtmgp_hip_version().startswith(b"0.4.0")   # (+ " [flags]" for a build that is not the shipped one)
+    assert _lib.lib().rrtmgp_hip_version().startswith(b"0.5.0")   # (+ " [flags]" for a build that is not the shipped one)
 
 
 def test_mcica_stream_matches_spec():
