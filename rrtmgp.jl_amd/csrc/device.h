@@ -487,9 +487,9 @@ __host__ __device__ inline size_t carve_shared(ColShared<FT, CHK> &s, char *base
     return (size_t)(p - base);
 }
 
-// Fill the TabCache (once per workgroup) and return a lookup view whose small-table pointers are the LDS copies.
+// Fill the TabCache (once per workgroup); cold_gas_view() builds the lookup view whose small-table pointers are these copies.
 template <typename FT, int CHK>
-__device__ inline DevGas<FT> cache_small_tables(const ColShared<FT, CHK> &sh, const ColDims &d, const DevGas<FT> &lk,
+__device__ inline void cache_small_tables(const ColShared<FT, CHK> &sh, const ColDims &d, const DevGas<FT> &lk,
                                                 const DevState<FT> &as) {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (as.vmr_kind == RRTMGP_VMR_GM)
@@ -503,14 +503,95 @@ __device__ inline DevGas<FT> cache_small_tables(const ColShared<FT, CHK> &sh, co
     for (int i = tid; i < 4 * d.nint1; i += nt) sh.tab_gasdata[1][i] = lk.m_gasdata[1][i];
     for (int i = tid; i < d.nslot0; i += nt) sh.tab_slot_int[0][i] = lk.m_slot_int[0][i];
     for (int i = tid; i < d.nslot1; i += nt) sh.tab_slot_int[1][i] = lk.m_slot_int[1][i];
-    DevGas<FT> v = lk;
+    __syncthreads();
+}
+
+// ---- cold kernel arguments ------------------------------------------------------------------------------------------
+// The column kernels take ONE by-value argument struct (LwArgs / SwArgs: ~100 pointers and sizes).  Read as `a.member` the
+// compiler loads every member it ever needs at kernel entry and keeps it in SGPRs for the whole kernel: ~100 live scalar
+// registers, 260-340 of them spilled to VGPR lanes, and the preparation phases (which use most of the pointers: state,
+// cloud, aerosol, flux arrays) spent 30 % of their instructions on v_readlane_b32 + hazard nops getting them back
+// (round-5 review).  Only the layer loops' own operands (table arena, strides, sweep scratch) are worth a register for the
+// length of a column.  Everything else is read WHERE IT IS USED, straight from the kernarg segment with s_load (constant
+// address space, scalar cache), at an offset made opaque so that the load is neither hoisted out of the column loop nor
+// kept alive across the layer loops:
+//   const DevState<FT> as = cold_state<FT>(offsetof(LwArgs<FT>, as));     // inside the column loop, next to its uses
+// A pointer that was loaded from memory has no known address space (accesses through it would be flat_load / flat_store
+// with 64-bit VGPR addresses): global_ptr() re-types it as a global pointer, which is what the by-value path gets from
+// clang's kernel-argument coercion.
+template <typename T>
+__device__ __forceinline__ T kernarg_load(unsigned offset) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    asm volatile("" : "+s"(offset));   // opaque: the loads below stay behind this point of the program
+    typedef __attribute__((address_space(4))) const unsigned cu32;
+    cu32 *p = (cu32 *)((__attribute__((address_space(4))) const char *)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = p[i];
+    T v;
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T *global_ptr(T *p) {
+    return (T *)(__attribute__((address_space(1))) T *)(unsigned long long)p;
+}
+template <typename T>
+__device__ __forceinline__ T *kernarg_ptr(unsigned offset) { return global_ptr(kernarg_load<T *>(offset)); }
+
+template <typename FT>
+__device__ __forceinline__ DevState<FT> cold_state(unsigned offset) {
+    DevState<FT> s = kernarg_load<DevState<FT>>(offset);
+    s.layerdata = global_ptr(s.layerdata); s.t_lev = global_ptr(s.t_lev); s.t_sfc = global_ptr(s.t_sfc);
+    s.vmr_h2o = global_ptr(s.vmr_h2o); s.vmr_o3 = global_ptr(s.vmr_o3); s.vmr = global_ptr(s.vmr);
+    s.cld_r_eff_liq = global_ptr(s.cld_r_eff_liq); s.cld_r_eff_ice = global_ptr(s.cld_r_eff_ice);
+    s.cld_path_liq = global_ptr(s.cld_path_liq); s.cld_path_ice = global_ptr(s.cld_path_ice);
+    s.cld_frac = global_ptr(s.cld_frac); s.cld_cover = global_ptr(s.cld_cover);
+    s.aero_size = global_ptr(s.aero_size); s.aero_mass = global_ptr(s.aero_mass);
+    s.aod_sw_ext = global_ptr(s.aod_sw_ext); s.aod_sw_sca = global_ptr(s.aod_sw_sca);
+    return s;
+}
+template <typename FT>
+__device__ __forceinline__ DevCld<FT> cold_cld(unsigned offset) {
+    DevCld<FT> c = kernarg_load<DevCld<FT>>(offset);
+    c.liqdata = global_ptr(c.liqdata); c.icedata = global_ptr(c.icedata);
+    return c;
+}
+template <typename FT>
+__device__ __forceinline__ DevAero<FT> cold_aero(unsigned offset) {
+    DevAero<FT> a = kernarg_load<DevAero<FT>>(offset);
+    a.size_bin_limits = global_ptr(a.size_bin_limits); a.rh_levels = global_ptr(a.rh_levels); a.dust = global_ptr(a.dust);
+    a.sea_salt = global_ptr(a.sea_salt); a.sulfate = global_ptr(a.sulfate); a.black_carbon_rh = global_ptr(a.black_carbon_rh);
+    a.black_carbon = global_ptr(a.black_carbon); a.organic_carbon_rh = global_ptr(a.organic_carbon_rh);
+    a.organic_carbon = global_ptr(a.organic_carbon);
+    return a;
+}
+template <typename FT>
+__device__ __forceinline__ DevFlux<FT> cold_flux(unsigned offset) {
+    DevFlux<FT> f = kernarg_load<DevFlux<FT>>(offset);
+    f.up = global_ptr(f.up); f.dn = global_ptr(f.dn); f.net = global_ptr(f.net); f.dir = global_ptr(f.dir);
+    f.metric = global_ptr(f.metric);
+    f.band_up = global_ptr(f.band_up); f.band_dn = global_ptr(f.band_dn); f.band_net = global_ptr(f.band_net);
+    f.clear_up = global_ptr(f.clear_up); f.clear_dn = global_ptr(f.clear_dn); f.clear_net = global_ptr(f.clear_net);
+    f.clear_dir = global_ptr(f.clear_dir);
+    return f;
+}
+// The lookup as the preparation steps see it: sizes and the Planck table from the kernarg segment, the small tables they
+// index with data-dependent positions from their LDS copies (TabCache, filled once per workgroup by cache_small_tables).
+template <typename FT, int CHK>
+__device__ __forceinline__ DevGas<FT> gas_view(DevGas<FT> v, const ColShared<FT, CHK> &sh, const ColDims &d) {
     v.t_ref = sh.tab_t_ref; v.ln_p_ref = sh.tab_ln_p_ref; v.eta_half = sh.tab_eta_half;
     if (d.lw) v.t_planck = sh.tab_t_planck;
     v.key_species = sh.tab_key_species;
     v.m_gasdata[0] = sh.tab_gasdata[0]; v.m_gasdata[1] = sh.tab_gasdata[1];
     v.m_slot_int[0] = sh.tab_slot_int[0]; v.m_slot_int[1] = sh.tab_slot_int[1];
-    __syncthreads();
     return v;
+}
+template <typename FT, int CHK>
+__device__ __forceinline__ DevGas<FT> cold_gas_view(unsigned offset, const ColShared<FT, CHK> &sh, const ColDims &d) {
+    DevGas<FT> v = kernarg_load<DevGas<FT>>(offset);
+    v.tot_planck = global_ptr(v.tot_planck); v.band_row_lo = global_ptr(v.band_row_lo);
+    return gas_view(v, sh, d);
 }
 
 // ---- g-point independent column preparation (lane = layer) --------------------------
@@ -1291,19 +1372,31 @@ __device__ __forceinline__ void queue_release(int *queue) {
 // ---- sweep scratch: NV values per (level, lane), lane-contiguous (3; 6 when the clear-sky
 // recurrences are carried next to the all-sky ones) ----------------------------------------
 constexpr int SWEEP_LANES = 256;  // lanes per scratch row, whatever the workgroup size (<= 256 g-points per lookup)
+typedef unsigned sweep_u2 __attribute__((ext_vector_type(2)));
 template <typename FT, int NV = 3>
 struct Sweep {
-    char *base;     // this workgroup's slab (wave-uniform)
+    // The slab of this workgroup as a BUFFER resource (4 SGPRs).  A buffer access forms its address from the resource base,
+    // one 32-bit VGPR offset (the lane: it never changes), one 32-bit SGPR offset (the row: wave-uniform, scalar arithmetic)
+    // and an immediate - no vector instruction computes an address.  As global_load / global_store with one 32-bit offset
+    // sum (rounds 2-5) every access of the second sweep cost a v_add_u32 (48 of the ~240 VALU instructions of a 16-level
+    // batch): the compiler cannot fold an unsigned 32-bit term into the 64-bit address, and written as 64-bit pointer
+    // arithmetic it re-associates the lane into the base and adds the level with v_lshl_add_u64 per level.
+    __amdgpu_buffer_rsrc_t rsrc;
     unsigned lane;  // threadIdx.x * sizeof(FT)
-    static constexpr unsigned row = SWEEP_LANES * sizeof(FT);  // a compile-time stride: neighbouring rows are immediate offsets
-    __device__ __forceinline__ FT *ptr(int lev, int a) const {
-        return reinterpret_cast<FT *>(base + ((unsigned)(lev * NV + a) * row + lane));
-    }
+    static constexpr unsigned row = SWEEP_LANES * sizeof(FT);  // a compile-time stride
+    static constexpr int AUX_LD = RR_SWEEP_NT >= 1 ? 2 : 0, AUX_ST = RR_SWEEP_NT >= 2 ? 2 : 0;   // nt bit (experiments)
+    __device__ __forceinline__ Sweep(FT *slab, size_t bytes, unsigned tid)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000)),
+          lane(tid * (unsigned)sizeof(FT)) {}
     __device__ __forceinline__ void put(int lev, int a, FT v) const {
-        if (RR_SWEEP_NT >= 2) __builtin_nontemporal_store(v, ptr(lev, a)); else *ptr(lev, a) = v;
+        const int so = (lev * NV + a) * (int)row;
+        if constexpr (sizeof(FT) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, lane, so, AUX_ST);
+        else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sweep_u2, v), rsrc, lane, so, AUX_ST);
     }
     __device__ __forceinline__ FT get(int lev, int a) const {
-        return RR_SWEEP_NT >= 1 ? __builtin_nontemporal_load(ptr(lev, a)) : *ptr(lev, a);
+        const int so = (lev * NV + a) * (int)row;
+        if constexpr (sizeof(FT) == 4) return __builtin_bit_cast(FT, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane, so, AUX_LD));
+        else return __builtin_bit_cast(FT, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane, so, AUX_LD));
     }
     // Three values of one level at once (a = 0, or 3 for the clear-sky twin): three rows, three 4-byte accesses per lane.
     // ([level][lane] records, one access per lane and level, were measured twice: 12-byte records in round 3, and 16-byte

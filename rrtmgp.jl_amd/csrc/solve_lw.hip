@@ -136,8 +136,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
     dd.diag = DIAG;  // what the host set, as a constant: the other flux set's pointers are never loaded
-    DevFlux<FT> fl_out = a.fl;
-    if (!BAND) fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+    dd.lw = 1; dd.twostream = 1;   // likewise (the preparation steps branch on them)
     const ColDims &d = dd;
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
@@ -150,23 +149,32 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 4 : 2;  // accumulated components per level: up, dn (+ clear up, dn)
-    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
+    const Sweep<FT, NV> sw(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES, (size_t)nlev * NV * SWEEP_LANES * sizeof(FT), (unsigned)tid);
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CHK - 1) / CHK;
-    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
+    cache_small_tables(sh, d, a.lk, a.as);
+    // Everything below that is not an operand of the layer loops is read from the kernarg segment where it is used
+    // (device.h, "cold kernel arguments"): offsets of the members of the one kernel argument
+#define RR_ARG(member) ((unsigned)offsetof(LwArgs<FT>, member))
 
     for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
-        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
+        {
+            const DevState<FT> as = cold_state<FT>(RR_ARG(as));
+            const DevCld<FT> cld = cold_cld<FT>(RR_ARG(cld));
+            const DevAero<FT> aero = cold_aero<FT>(RR_ARG(aero));
+            prepare_column(sh, d, cold_gas_view<FT>(RR_ARG(lk), sh, d), &cld, &aero, as, col);
+        }
 
         uint64_t m0 = 0, m1 = 0;
         if (d.has_cld) {
-            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 0);
+            const uint64_t key = mcica_key(kernarg_load<uint64_t>(RR_ARG(seed)), kernarg_load<int64_t>(RR_ARG(col_offset)) + col + 1, g + 1, 0);
             const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
             const unsigned long long b = __ballot(cloudy);
             if (lane == 0) sh.misc[wave] = __popcll(b);
         }
-        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
-        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)a.inc_ld * g] : FT(0);
+        const FT emis = kernarg_ptr<const FT>(RR_ARG(sfc_emis))[(size_t)lb.ibnd + (size_t)nb * col];
+        const FT *inc_flux = kernarg_ptr<const FT>(RR_ARG(inc_flux));
+        const FT inc = inc_flux ? inc_flux[(size_t)col + (size_t)kernarg_load<int>(RR_ARG(inc_ld)) * g] : FT(0);
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
         FT sfc_source = FT(0);
@@ -205,6 +213,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
         FT tau_pc = FT(0), ssa_pc = FT(0), g_pc = FT(0);   // ... without the cloud increment (DIAG)
         bool cld_p = false;
         FT lev_top = FT(0), dec_p = FT(0);                 // lev_source[k+2], B(t_lev[k+1]) * pfrac[k+1]
+        FT pfrac = FT(0);                                  // Planck fraction of the current layer (after the loop: of layer 0)
         auto adding = [&](Stream &t, FT Rdif, FT Tdif, FT src_up, FT src_dn, int kl, int voff, int aoff, bool also_twin) {
             const FT den = m_rcp(FT(1) - t.beta * Rdif);
             sw.put3(kl, voff, Tdif * den /* A */, (Rdif * t.delta + src_up) * den /* B */, t.beta);
@@ -243,11 +252,16 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             const int k0 = c * CHK, kn = min(CHK, nlay - k0);
             mw.refill(k0 + kn - 1);
             __syncthreads();
-            prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
+            {
+                const DevState<FT> as = cold_state<FT>(RR_ARG(as));
+                const DevCld<FT> cld = cold_cld<FT>(RR_ARG(cld));
+                const DevAero<FT> aero = cold_aero<FT>(RR_ARG(aero));
+                prepare_chunk(sh, d, cold_gas_view<FT>(RR_ARG(lk), sh, d), &cld, &aero, as, col, k0, kn, false);
+            }
             __syncthreads();
             for (int kk = kn - 1; kk >= 0; kk--) {
                 const int k = k0 + kk;
-                FT tau, ssa, gg, pfrac;
+                FT tau, ssa, gg;
                 FT tau_c = FT(0), ssa_c = FT(0), g_c = FT(0);
                 bool cld_k = false;
                 if (DIAG) {
@@ -267,11 +281,11 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 dec_p = lev_src_dec;
                 tau_p = tau; ssa_p = ssa; g_p = gg;
                 if (DIAG) { tau_pc = tau_c; ssa_pc = ssa_c; g_pc = g_c; cld_p = cld_k; }
-                if (k == 0) {
-                    const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
-                    sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
-                }
             }
+        }
+        {   // surface source: the Planck function at t_sfc times the Planck fraction of the lowest layer (the loop's last)
+            const FT *tp = kernarg_ptr<const FT>(RR_ARG(lk.tot_planck)) + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+            sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
         }
         add_layer(0, dec_p);  // lev_source[1] = lev_src_dec of the first layer
         // ---- surface: U_1 = (1 - emis) D_1 + pi emis B_sfc,  D_1 = beta_1 U_1 + delta_1 ----
@@ -306,12 +320,21 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions (wave_sum16)
+                    if (kl + 16 <= k_end) {   // a whole batch (wave-uniform): no per-level selects
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const bool in = kl + j < k_end;
-                        if (in) U = A[j] * U + B[j];
-                        pu[j] = in ? U * amask : FT(0);
-                        pb[j] = in ? BE[j] * U * amask : FT(0);
+                        for (int j = 0; j < 16; j++) {
+                            U = A[j] * U + B[j];
+                            pu[j] = U * amask;
+                            pb[j] = BE[j] * U * amask;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const bool in = kl + j < k_end;
+                            if (in) U = A[j] * U + B[j];
+                            pu[j] = in ? U * amask : FT(0);
+                            pb[j] = in ? BE[j] * U * amask : FT(0);
+                        }
                     }
                     FT wu[4], wb[4];
                     wave_sum16(pu, wu);
@@ -376,12 +399,22 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             }
             if (!BAND) {
                 FT pu[16], pc[16];   // 16 g-point sums per stream in one 16-value reduction
+                if (kl + 16 <= nlay) {   // a whole batch (wave-uniform): no per-level selects
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const bool in = kl + j < nlay;
-                    if (in) { U = A[j] * U + B[j]; if (DIAG) Uc = A[j] * Uc + B[j]; }
-                    pu[j] = in ? U * amask : FT(0);
-                    pc[j] = DIAG && in ? Uc * amask : FT(0);
+                    for (int j = 0; j < 16; j++) {
+                        U = A[j] * U + B[j];
+                        if (DIAG) Uc = A[j] * Uc + B[j];
+                        pu[j] = U * amask;
+                        pc[j] = DIAG ? Uc * amask : FT(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const bool in = kl + j < nlay;
+                        if (in) { U = A[j] * U + B[j]; if (DIAG) Uc = A[j] * Uc + B[j]; }
+                        pu[j] = in ? U * amask : FT(0);
+                        pc[j] = DIAG && in ? Uc * amask : FT(0);
+                    }
                 }
                 FT wu[4], wc[4];
                 wave_sum16(pu, wu);
@@ -414,14 +447,22 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             }
         }
         __syncthreads();
-        store_column(fl_out, sh, d, col, ncol, false, a.lk);
-        if (d.has_cld && a.as.cld_cover && tid == 0) {
-            int n = 0;
-            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
-            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
+        {
+            DevFlux<FT> fl_out = cold_flux<FT>(RR_ARG(fl));
+            if (!BAND) fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+            store_column(fl_out, sh, d, col, ncol, false, cold_gas_view<FT>(RR_ARG(lk), sh, d));
+        }
+        if (d.has_cld && tid == 0) {
+            FT *cover = kernarg_ptr<FT>(RR_ARG(as.cld_cover));
+            if (cover) {
+                int n = 0;
+                for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+                cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient
+            }
         }
     }
     queue_release(a.queue);
+#undef RR_ARG
 }
 
 // fact of rte_lw_noscat_one_angle! (longwave_noscat.jl:178-180): (1 - t) / tau - t, or its series below tau_thresh.
@@ -457,8 +498,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
     ColShared<FT, CHK> sh;
     ColDims dd = a.dims;
     dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; dd.diag = 0;
-    DevFlux<FT> fl_out = a.fl;
-    fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+    dd.lw = 1; dd.twostream = 0;
     const ColDims &d = dd;
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
@@ -469,26 +509,33 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
     const LaneBand lb = lane_band(a.lk, g);
     constexpr bool ONE = NANG == 1;
     constexpr int NV = ONE ? 2 : 3;  // per level: (trans, src_up), or (tau, B_lay, B_lev_top)
-    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
+    const Sweep<FT, NV> sw(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES, (size_t)nlev * NV * SWEEP_LANES * sizeof(FT), (unsigned)tid);
     const FT amask = active ? FT(1) : FT(0);
     const int nchunk = (nlay + CHK - 1) / CHK;
-    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);
+    cache_small_tables(sh, d, a.lk, a.as);
+#define RR_ARG(member) ((unsigned)offsetof(LwArgs<FT>, member))   // cold kernel arguments: device.h
     const FT tthresh = tau_thresh<FT>();
     FT Ds[NANG], rD[NANG], i2f[NANG];
 #pragma unroll
     for (int s = 0; s < NANG; s++) { Ds[s] = a.Ds[s]; rD[s] = FT(1) / a.Ds[s]; i2f[s] = Num<FT>::pi() * a.wts[s]; }
 
     for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
-        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
+        {
+            const DevState<FT> as = cold_state<FT>(RR_ARG(as));
+            const DevCld<FT> cld = cold_cld<FT>(RR_ARG(cld));
+            const DevAero<FT> aero = cold_aero<FT>(RR_ARG(aero));
+            prepare_column(sh, d, cold_gas_view<FT>(RR_ARG(lk), sh, d), &cld, &aero, as, col);
+        }
         uint64_t m0 = 0, m1 = 0;
         if (d.has_cld) {
-            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 0);
+            const uint64_t key = mcica_key(kernarg_load<uint64_t>(RR_ARG(seed)), kernarg_load<int64_t>(RR_ARG(col_offset)) + col + 1, g + 1, 0);
             const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
             const unsigned long long b = __ballot(cloudy);
             if (lane == 0) sh.misc[wave] = __popcll(b);
         }
-        const FT emis = a.sfc_emis[(size_t)lb.ibnd + (size_t)nb * col];
-        const FT inc = a.inc_flux ? a.inc_flux[(size_t)col + (size_t)a.inc_ld * g] : FT(0);
+        const FT emis = kernarg_ptr<const FT>(RR_ARG(sfc_emis))[(size_t)lb.ibnd + (size_t)nb * col];
+        const FT *inc_flux = kernarg_ptr<const FT>(RR_ARG(inc_flux));
+        const FT inc = inc_flux ? inc_flux[(size_t)col + (size_t)kernarg_load<int>(RR_ARG(inc_ld)) * g] : FT(0);
         FT *acc = sh.acc + (size_t)wave * nlev * 2;
         const bool writer = lane == 63;
         MaskWalk<false> mw(m0, m1, nlay, sh.mask);  // top-down
@@ -497,7 +544,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
         FT I[NANG];
         FT f = FT(0);
 #pragma unroll
-        for (int s = 0; s < NANG; s++) { I[s] = a.inc_flux ? inc / Num<FT>::pi() : FT(0); f += I[s] * i2f[s]; }
+        for (int s = 0; s < NANG; s++) { I[s] = inc_flux ? inc / Num<FT>::pi() : FT(0); f += I[s] * i2f[s]; }
         {
             const FT sd = wave_sum_to_lane63(f * amask);
             if (writer) acc[nlay * 2 + 1] = sd;
@@ -517,16 +564,21 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             const FT sd = wave_sum_to_lane63(fs * amask);
             if (writer) acc[kp * 2 + 1] = sd;
         };
-        FT sfc_source = FT(0);
+        FT sfc_source = FT(0), pfrac = FT(0);   // pfrac: Planck fraction of the current layer (after the loop: of layer 0)
         for (int c = nchunk - 1; c >= 0; c--) {
             const int k0 = c * CHK, kn = min(CHK, nlay - k0);
             mw.refill(k0 + kn - 1);
             __syncthreads();
-            prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, false);
+            {
+                const DevState<FT> as = cold_state<FT>(RR_ARG(as));
+                const DevCld<FT> cld = cold_cld<FT>(RR_ARG(cld));
+                const DevAero<FT> aero = cold_aero<FT>(RR_ARG(aero));
+                prepare_chunk(sh, d, cold_gas_view<FT>(RR_ARG(lk), sh, d), &cld, &aero, as, col, k0, kn, false);
+            }
             __syncthreads();
             for (int kk = kn - 1; kk >= 0; kk--) {
                 const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
-                FT tau, ssa, pfrac;
+                FT tau, ssa;
                 gas_optics<FT, false>(a.lk, sh, lb, k, kk, nb, tau, ssa, pfrac);
                 // OneScalar: clouds and aerosols add their absorption optical depth (cloud_optics.jl:45, aerosol_optics.jl:45)
                 if (d.has_cld && mw.next(k)) tau += sh.ch->cld[r].x;
@@ -552,11 +604,11 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
                 }
                 if (!ONE) { sw.put(k, 0, tau); sw.put(k, 1, lay_src); sw.put(k, 2, lev_up); }
                 lay_p = lay_src; dec_p = dec;
-                if (k == 0) {
-                    const FT *tp = a.lk.tot_planck + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
-                    sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;  // compute_optical_props.jl:184-186
-                }
             }
+        }
+        {   // compute_optical_props.jl:184-186: the Planck function at t_sfc times the Planck fraction of the lowest layer
+            const FT *tp = kernarg_ptr<const FT>(RR_ARG(lk.tot_planck)) + (size_t)a.lk.n_t_plnk * lb.ibnd + sh.misc[d.nwaves];
+            sfc_source = (tp[0] * (FT(1) - sh.miscf[0]) + tp[1] * sh.miscf[0]) * pfrac;
         }
         step_down(0, dec_p);  // lev_source[1] = lev_dec of the first layer
         // surface: I_up = I_dn (1 - emis) + emis B_sfc (:262-266)
@@ -616,14 +668,22 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? RR_MIN_WAVES : 2)) lw_
             }
         }
         __syncthreads();
-        store_column(fl_out, sh, d, col, ncol, false, a.lk);
-        if (d.has_cld && a.as.cld_cover && tid == 0) {
-            int n = 0;
-            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
-            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);
+        {
+            DevFlux<FT> fl_out = cold_flux<FT>(RR_ARG(fl));
+            fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+            store_column(fl_out, sh, d, col, ncol, false, cold_gas_view<FT>(RR_ARG(lk), sh, d));
+        }
+        if (d.has_cld && tid == 0) {
+            FT *cover = kernarg_ptr<FT>(RR_ARG(as.cld_cover));
+            if (cover) {
+                int n = 0;
+                for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+                cover[col] = (FT)((double)n / (double)a.lk.n_gpt);
+            }
         }
     }
     queue_release(a.queue);
+#undef RR_ARG
 }
 
 // Gauss-Jacobi-5 secants and weights, src/optics/AngularDiscretizations.jl:41-56

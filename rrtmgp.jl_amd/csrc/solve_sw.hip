@@ -94,8 +94,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
     ColDims dd = a.dims;
     if (CA >= 0) { dd.has_cld = CA & 1; dd.has_aero = (CA >> 1) & 1; }
     dd.diag = DIAG;  // what the host set, as a constant: the other flux set's pointers are never loaded
-    DevFlux<FT> fl_out = a.fl;
-    if (!BAND) fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+    dd.lw = 0; dd.twostream = TWOSTREAM;   // likewise (the preparation steps branch on them)
     const ColDims &d = dd;
     carve_shared(sh, smem, d);
     const int nlay = d.nlay, nlev = d.nlev, ncol = a.as.ncol, nb = d.nbnd;
@@ -108,27 +107,58 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
     const LaneBand lb = lane_band(a.lk, g);
     constexpr int NV = DIAG ? 6 : 3;  // sweep values per level
     constexpr int NA = DIAG ? 6 : 3;  // accumulated components per level: up, dn, dir (+ the clear-sky three)
-    Sweep<FT, NV> sw{(char *)(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES), (unsigned)(tid * sizeof(FT))};
+    const Sweep<FT, NV> sw(a.scratch + (size_t)blockIdx.x * (size_t)nlev * NV * SWEEP_LANES, (size_t)nlev * NV * SWEEP_LANES * sizeof(FT), (unsigned)tid);
     const FT amask = active ? FT(1) : FT(0);
     const FT solar_frac = a.lk.solar_src_scaled[g];
     const int nchunk = (nlay + CHK - 1) / CHK;
-    const DevGas<FT> lkp = cache_small_tables(sh, d, a.lk, a.as);  // lookup view for the preparation steps
+    cache_small_tables(sh, d, a.lk, a.as);
     const bool want_aod = d.has_aero && a.aero.iband_550nm > 0 && a.as.aod_sw_ext != nullptr;
+    // Everything below that is not an operand of the layer loops is read from the kernarg segment where it is used
+    // (device.h, "cold kernel arguments"): offsets of the members of the one kernel argument
+#define RR_ARG(member) ((unsigned)offsetof(SwArgs<FT>, member))
+    // (one instance keeps the by-value form: clouds + aerosols without the diagnostic, whose layer loop the register
+    // allocator serves worse with the cold form - 13 SGPR reloads per layer, SW 17.75 -> 18.4 ms; tools/experiments/README.md)
+#ifndef RR_SW3_COLD
+#define RR_SW3_COLD 0
+#endif
+    constexpr bool COLD = RR_SW3_COLD || !(CA == 3 && !DIAG && !BAND);
+    auto arg_state = [&]() -> DevState<FT> { if constexpr (COLD) return cold_state<FT>(RR_ARG(as)); else return a.as; };
+    auto arg_cld = [&]() -> DevCld<FT> { if constexpr (COLD) return cold_cld<FT>(RR_ARG(cld)); else return a.cld; };
+    auto arg_aero = [&]() -> DevAero<FT> { if constexpr (COLD) return cold_aero<FT>(RR_ARG(aero)); else return a.aero; };
+    auto arg_lk = [&]() -> DevGas<FT> { if constexpr (COLD) return cold_gas_view<FT>(RR_ARG(lk), sh, d); else return gas_view(a.lk, sh, d); };
+    auto store = [&](int col, bool zero) {
+        DevFlux<FT> fl_out;
+        if constexpr (COLD) fl_out = cold_flux<FT>(RR_ARG(fl)); else fl_out = a.fl;
+        if (!BAND) fl_out.band_up = fl_out.band_dn = fl_out.band_net = nullptr;
+        store_column(fl_out, sh, d, col, ncol, zero, arg_lk());
+    };
+    auto chunk = [&](int col, int k0, int kn) {   // prepare_chunk with its arguments read where they are used
+        const DevState<FT> as = arg_state();
+        const DevCld<FT> cld = arg_cld();
+        const DevAero<FT> aero = arg_aero();
+        prepare_chunk(sh, d, arg_lk(), &cld, &aero, as, col, k0, kn, true);
+    };
 
     for (int col = blockIdx.x; col < ncol; col = next_column(sh, d, a.queue)) {
-        const FT mu0 = a.cos_zenith[col];
+        const FT mu0 = kernarg_ptr<const FT>(RR_ARG(cos_zenith))[col];
         const bool day = mu0 > FT(0);
         if (!TWOSTREAM && !day) {  // shortwave_noscat.jl:86-99: nothing runs for night columns
-            store_column(fl_out, sh, d, col, ncol, true, a.lk);
+            store(col, true);
             continue;
         }
-        prepare_column(sh, d, lkp, &a.cld, &a.aero, a.as, col);
+        {
+            const DevState<FT> as = arg_state();
+            const DevCld<FT> cld = arg_cld();
+            const DevAero<FT> aero = arg_aero();
+            prepare_column(sh, d, arg_lk(), &cld, &aero, as, col);
+        }
+        const FT toa_flux = kernarg_ptr<const FT>(RR_ARG(toa_flux))[col];
         FT *acc = sh.acc + (size_t)(BAND ? tid >> 4 : wave) * nlev * NA;
         const bool writer = BAND ? (lane & 15) == 15 : lane == 63;
 
         if (!TWOSTREAM) {
             // rte_sw_noscat!, shortwave_noscat.jl:120-148 (multiplicative Beer-Lambert, flux_up = 0)
-            FT dir = a.toa_flux[col] * solar_frac * mu0;
+            FT dir = toa_flux * solar_frac * mu0;
             {
                 const FT s = seg_sum<BAND>(dir * amask);
                 if (writer) { acc[nlay * 3] = FT(0); acc[nlay * 3 + 1] = s; acc[nlay * 3 + 2] = s; }
@@ -136,7 +166,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             for (int c = nchunk - 1; c >= 0; c--) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                chunk(col, k0, kn);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk;
@@ -148,14 +178,14 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 }
             }
             __syncthreads();
-            store_column(fl_out, sh, d, col, ncol, false, a.lk);
+            store(col, false);
             __syncthreads();
             continue;
         }
 
         uint64_t m0 = 0, m1 = 0;
         if (d.has_cld) {
-            const uint64_t key = mcica_key(a.seed, a.col_offset + col + 1, g + 1, 1);
+            const uint64_t key = mcica_key(kernarg_load<uint64_t>(RR_ARG(seed)), kernarg_load<int64_t>(RR_ARG(col_offset)) + col + 1, g + 1, 1);
             const bool cloudy = build_cloud_mask(sh, d, key, m0, m1) && active;
             const unsigned long long b = __ballot(cloudy);
             if (lane == 0) sh.misc[wave] = __popcll(b);
@@ -173,7 +203,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             //     delta_k = S_dn + T den (delta_{k+1} + beta_{k+1} S_up),
             // which is the mirror image of Eqs 9-11 and gives the same fluxes.  One sweep fewer, and
             // 3 stored values per level; delta only enters D additively, so it is summed on the fly. ----
-            const FT dir_top = a.toa_flux[col] * solar_frac * mu0;
+            const FT dir_top = toa_flux * solar_frac * mu0;
             const FT inv_mu0 = FT(1) / m_max(mu0, mu0_min<FT>());
             // one stream of the top-down adding: all-sky, and (DIAG) its clear-sky twin
             struct Stream { FT tau_cum, dir_above, beta, delta; };
@@ -227,7 +257,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 mw.refill(k0 + kn - 1);
                 __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                chunk(col, k0, kn);
                 __syncthreads();
                 for (int kk = kn - 1; kk >= 0; kk--) {
                     const int k = k0 + kk, r = kk * NBMAX + lb.ibnd;
@@ -255,8 +285,8 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 }
             }
             // ---- surface: U_1 = alb_dif D_1 + dir_sfc alb_dir, D_1 = beta_1 U_1 + delta_1 ----
-            const FT alb = a.alb_dif[(size_t)lb.ibnd + (size_t)nb * col];
-            const FT alb_d = a.alb_dir[(size_t)lb.ibnd + (size_t)nb * col];
+            const FT alb = kernarg_ptr<const FT>(RR_ARG(alb_dif))[(size_t)lb.ibnd + (size_t)nb * col];
+            const FT alb_d = kernarg_ptr<const FT>(RR_ARG(alb_dir))[(size_t)lb.ibnd + (size_t)nb * col];
             FT U = m_div(alb * S.delta + S.dir_above * alb_d, FT(1) - alb * S.beta);
             FT Uc = DIAG ? m_div(alb * C.delta + C.dir_above * alb_d, FT(1) - alb * C.beta) : FT(0);
             {
@@ -286,12 +316,21 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
                 }
                 if (!BAND && !DIAG && DBT == 16) {
                     FT pu[16], pb[16];  // the 2 x 16 g-point sums of the batch in two 16-value reductions
+                    if (kl + 16 <= k_end) {   // a whole batch (wave-uniform): no per-level selects
 #pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const bool in = kl + j < k_end;
-                        if (in) U = A[j] * U + B[j];
-                        pu[j] = in ? U * amask : FT(0);
-                        pb[j] = in ? BE[j] * U * amask : FT(0);
+                        for (int j = 0; j < 16; j++) {
+                            U = A[j] * U + B[j];
+                            pu[j] = U * amask;
+                            pb[j] = BE[j] * U * amask;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const bool in = kl + j < k_end;
+                            if (in) U = A[j] * U + B[j];
+                            pu[j] = in ? U * amask : FT(0);
+                            pb[j] = in ? BE[j] * U * amask : FT(0);
+                        }
                     }
                     FT wu[4], wb[4];
                     wave_sum16(pu, wu);
@@ -357,7 +396,7 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             for (int c = 0; c < nchunk; c++) {
                 const int k0 = c * CHK, kn = min(CHK, nlay - k0);
                 __syncthreads();
-                prepare_chunk(sh, d, lkp, &a.cld, &a.aero, a.as, col, k0, kn, true);
+                chunk(col, k0, kn);
             }
         }
         __syncthreads();
@@ -366,17 +405,21 @@ __global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR
             FT e = FT(0), s = FT(0);
             for (int k = 0; k < nlay; k++)
                 if (sh.lay[k].aero_mask) { e += sh.lay[k].aod_t; s += sh.lay[k].aod_ts; }
-            a.as.aod_sw_ext[col] = e;
-            a.as.aod_sw_sca[col] = s;
+            kernarg_ptr<FT>(RR_ARG(as.aod_sw_ext))[col] = e;
+            kernarg_ptr<FT>(RR_ARG(as.aod_sw_sca))[col] = s;
         }
-        store_column(fl_out, sh, d, col, ncol, !day, a.lk);
-        if (d.has_cld && a.as.cld_cover && tid == 0) {
-            int n = 0;
-            for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
-            a.as.cld_cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient (the Float32 build divides in 2.5 ulp)
+        store(col, !day);
+        if (d.has_cld && tid == 0) {
+            FT *cover = kernarg_ptr<FT>(RR_ARG(as.cld_cover));
+            if (cover) {
+                int n = 0;
+                for (int w = 0; w < d.nwaves; w++) n += sh.misc[w];
+                cover[col] = (FT)((double)n / (double)a.lk.n_gpt);  // exact quotient
+            }
         }
     }
     queue_release(a.queue);
+#undef RR_ARG
 }
 
 int column_grid(rrtmgp_workspace *ws, int ncol, int threads, size_t lds_bytes, const void *kernel);

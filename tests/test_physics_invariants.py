@@ -127,9 +127,9 @@ def test_layer_splitting_shortwave(tables64, backend, ft, sky):
     as_, _, sb = S.make_columns(ncol, nlay, ft, seed=31, clouds=full, aerosols=full, cld_frac=1.0)
     one = run_sw(backend, as_, sb, sw, cld, aero)
     two = run_sw(backend, split_layers(as_), sb, sw, cld, aero)
-    # Float64: composition is exact up to rounding (measured 3e-12 W/m2 on the oracle); Float32: the rounding of twice as
+    # Float64: composition is exact up to rounding (measured 3e-12 W/m2 on the oracle at 40 layers, 4e-9 on the GPU at 2 x 73 layers x 4096 columns with its 2-ulp Float64 exp); Float32: the rounding of twice as
     # many layers (measured 3e-3 on 1360 W/m2)
-    tol = 1e-9 if ft == np.float64 else 2.5e-2
+    tol = 2e-8 if ft == np.float64 else 2.5e-2
     assert one[1].max() > 100.0
     for name, a, b in zip(("flux_up", "flux_dn", "flux_dn_dir"), one, two):
         d = np.abs(a - b[0::2]).max()
@@ -166,7 +166,7 @@ def test_layer_splitting_longwave_isothermal(tables64, backend, ft, solver):
     kw = dict(twostream=solver == "2stream", n_angles=3 if solver == "noscat3" else 1)
     one = run_lw(backend, as_, lb, lw, cld, **kw)
     two = run_lw(backend, split_layers(as_), lb, lw, cld, **kw)
-    tol = 1e-9 if ft == np.float64 else 2e-3
+    tol = 2e-8 if ft == np.float64 else 2e-3
     for name, a, b in zip(("flux_up", "flux_dn"), one, two):
         assert a.max() > 100.0
         d = np.abs(a - b[0::2]).max()

@@ -11,7 +11,7 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("ISA_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize"]
 
 
@@ -42,7 +42,9 @@ def main():
             m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 loops.append((labels[m.group(1)], i))
-        print(name)
+        whole = [x.strip() for x in body if x.startswith("\t") and not x.strip().startswith((".", ";"))]
+        print(name, f"| {len(whole)} instr, static v_readlane {sum(x.startswith('v_readlane') for x in whole)} v_writelane {sum(x.startswith('v_writelane') for x in whole)} "
+                    f"flat {sum(x.startswith('flat_') for x in whole)} s_load {sum(x.startswith('s_load') for x in whole)} scratch {sum(x.startswith('scratch_') for x in whole)}")
         for a, b in sorted(set(loops)):
             ins = [x.strip() for x in body[a:b + 1] if x.startswith("\t") and not x.strip().startswith((".", ";"))]
             if len(ins) < mn:
@@ -50,7 +52,8 @@ def main():
             c = lambda p: sum(1 for x in ins if re.match(p, x))  # noqa: E731
             print(f"  loop lines {a}-{b}: {len(ins)} instr | VALU {c(r'v_')} (trans {c(r'v_(exp|log|rcp|rsq|sqrt|sin|cos)')}, dpp {sum('dpp' in x for x in ins)}, "
                   f"f64 {c(r'v_[a-z0-9_]+_f64')}) SALU {c(r's_(?!waitcnt|nop|cbranch|branch|barrier)')} | scratch {c(r'scratch_')} "
-                  f"gload {c(r'global_load')} gstore {c(r'global_store')} ds {c(r'ds_')} | waitcnt {c(r's_waitcnt')} nop {c(r's_nop')} barrier {c(r's_barrier')}")
+                  f"gload {c(r'global_load')} gstore {c(r'global_store')} flat {c(r'flat_')} sload {c(r's_load')} ds {c(r'ds_')} | waitcnt {c(r's_waitcnt')} nop {c(r's_nop')} "
+                  f"barrier {c(r's_barrier')} | readlane {c(r'v_readlane')} writelane {c(r'v_writelane')}")
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 # Usage: tools/resource_report.sh solve_lw|solve_sw [grep-pattern] [extra hipcc flags]
 cd "$(dirname "$0")/../rrtmgp.jl_amd/csrc"
 F=$1; PAT=${2:-.}; shift; shift
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt "$@" \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize "$@" \
   -Rpass-analysis=kernel-resource-usage -c $F.hip -o /tmp/rr_$F.o 2>&1 |
 python3 -c '
 import re, sys, subprocess
