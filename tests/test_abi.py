@@ -115,7 +115,7 @@ def test_header_is_plain_c_and_a_c_program_can_bind_it(tmp_path):
     libdir = os.path.dirname(_lib.SO_PATH)
     exe = str(tmp_path / "c_consumer")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "c_consumer.c"), "-L" + libdir, "-lhip_rrtmgp",
+                    os.path.join(ROOT, "examples", "c_consumer.c"), "-L" + libdir, "-lhip_rrtmgp", "-lm",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "0 problem(s)" in r.stdout, r.stdout + r.stderr
