@@ -12,7 +12,6 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
-#include <mutex>
 #include <thread>
 
 #include "common.h"
@@ -266,6 +265,27 @@ int queue_ensure(rrtmgp_workspace *ws, int lane_idx, int **out) {
         q = (int *)p;
     }
     *out = q;
+    return RRTMGP_OK;
+}
+
+// The column kernels leave their queue counters at {0, 0} (queue_release, device.h) and rely on finding them so: a kernel that
+// returned early, a new kernel that forgot queue_release, or a launch still running when the workspace moved to another
+// stream would leave them dirty and every later launch on the lane would silently skip or repeat columns.
+// Called where the lanes are known to be idle: reads both counters back and fails loudly instead.
+int queue_check(rrtmgp_workspace *ws, bool reset_only) {
+    for (int *q : ws->col_queue) {
+        if (!q) continue;
+        int v[2] = {0, 0};
+        if (!reset_only) RR_HIP(hipMemcpy(v, q, sizeof v, hipMemcpyDeviceToHost));
+        if (reset_only || v[0] || v[1]) {
+            RR_HIP(hipMemset(q, 0, 256));
+            RR_HIP(hipDeviceSynchronize());
+        }
+        if (v[0] || v[1])
+            return set_error(RRTMGP_EHIP, "internal: a column kernel left its queue counters at {" + std::to_string(v[0]) + ", " +
+                             std::to_string(v[1]) + "} (every kernel on the queue must end with queue_release); the results of the "
+                             "last launch on this workspace are not to be trusted.  The counters have been reset");
+    }
     return RRTMGP_OK;
 }
 
@@ -786,9 +806,12 @@ struct Stager {
 struct StateRW {
     bool core = false, particles = false;
 };
+// `nrghice`: roughness classes of the cloud lookup the solve uses; 0 = NO cloud lookup reads the cloud arrays (they are staged
+// for the isothermal-layer preparation only: whichever of them the state carries, and `ice_rgh` is nobody's business).
+// `aero_lookup` likewise for the aerosol arrays.
 template <typename FT>
 static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, bool use_aero, bool lw, DevState<FT> &d,
-                       int64_t nrghice = 1, StateRW rw = StateRW()) {
+                       int64_t nrghice = 1, StateRW rw = StateRW(), bool aero_lookup = true) {
     const size_t E = sizeof(FT), ncol = as->ncol, nlay = as->nlay, nlev = nlay + 1;
     RR_CHECK(as->layerdata && as->t_sfc && as->vmr, "atmospheric state: missing array");
     RR_CHECK(!lw || as->t_lev, "atmospheric state: t_lev is required for longwave");
@@ -811,24 +834,28 @@ static int stage_state(Stager &st, const rrtmgp_atmos_state *as, bool use_cld, b
     d.cld_cover = nullptr;
     d.ice_rgh = (int)as->ice_rgh;
     if (use_cld) {
-        RR_CHECK(as->cld_frac && as->cld_r_eff_liq && as->cld_r_eff_ice && as->cld_path_liq && as->cld_path_ice,
-                 "cloud lookup given but the state has no CloudState");
-        RR_CHECK(as->ice_rgh >= 1 && as->ice_rgh <= nrghice, "ice_rgh must be in 1..nrghice of the cloud lookup");
+        const bool lookup = nrghice > 0;
+        if (lookup) {
+            RR_CHECK(as->cld_frac && as->cld_r_eff_liq && as->cld_r_eff_ice && as->cld_path_liq && as->cld_path_ice,
+                     "cloud lookup given but the state has no CloudState");
+            RR_CHECK(as->ice_rgh >= 1 && as->ice_rgh <= nrghice, "ice_rgh must be in 1..nrghice of the cloud lookup");
+        }
+        // (st.io of a null array leaves the device pointer null: the preparation skips what the state does not carry)
         TRY(st.io(rw.particles, mem, S_CLD_RL, as->cld_r_eff_liq, nlay * ncol * E, (const void **)&d.cld_r_eff_liq));
         TRY(st.io(rw.particles, mem, S_CLD_RI, as->cld_r_eff_ice, nlay * ncol * E, (const void **)&d.cld_r_eff_ice));
         TRY(st.io(rw.particles, mem, S_CLD_PL, as->cld_path_liq, nlay * ncol * E, (const void **)&d.cld_path_liq));
         TRY(st.io(rw.particles, mem, S_CLD_PI, as->cld_path_ice, nlay * ncol * E, (const void **)&d.cld_path_ice));
         TRY(st.io(rw.particles, mem, S_CLD_F, as->cld_frac, nlay * ncol * E, (const void **)&d.cld_frac));
-        TRY(st.out(mem, S_CLD_COVER, lw ? as->cld_cover_lw : as->cld_cover_sw, ncol * E, (void **)&d.cld_cover));
+        if (lookup) TRY(st.out(mem, S_CLD_COVER, lw ? as->cld_cover_lw : as->cld_cover_sw, ncol * E, (void **)&d.cld_cover));
     }
     d.aero_size = d.aero_mass = nullptr;
     d.aod_sw_ext = d.aod_sw_sca = nullptr;
     if (use_aero) {
-        RR_CHECK(as->aero_size && as->aero_mass, "aerosol lookup given but the state has no AerosolState");
+        RR_CHECK(!aero_lookup || (as->aero_size && as->aero_mass), "aerosol lookup given but the state has no AerosolState");
         const size_t n = (size_t)RRTMGP_N_AEROSOLS * nlay * ncol * E;
         TRY(st.io(rw.particles, mem, S_AERO_SIZE, as->aero_size, n, (const void **)&d.aero_size));
         TRY(st.io(rw.particles, mem, S_AERO_MASS, as->aero_mass, n, (const void **)&d.aero_mass));
-        if (!lw) {
+        if (!lw && aero_lookup) {
             RR_CHECK((as->aod_sw_ext == nullptr) == (as->aod_sw_sca == nullptr), "aod_sw_ext and aod_sw_sca go together");
             TRY(st.out(mem, S_AOD_EXT, as->aod_sw_ext, ncol * E, (void **)&d.aod_sw_ext));
             TRY(st.out(mem, S_AOD_SCA, as->aod_sw_sca, ncol * E, (void **)&d.aod_sw_sca));
@@ -1475,9 +1502,11 @@ static void strided_copy(void *dense, void *strided, size_t n0, size_t n1, size_
 }
 // distinct (i, j) -> distinct elements?  Sufficient for every view Julia's `view` / numpy basic slicing can make of a dense
 // parent: one stride spans the other dimension entirely.
+// (The last element of a line along the faster dimension sits at (n - 1) * stride: the next line may start right behind it.
+// Round 5 asked for n * stride, which refused `view(A, 1:2:5, :)` of a 5-row parent: n0 = 3, s0 = 2, s1 = 5.  ADVICE r5.)
 static bool view_is_injective(size_t n0, size_t n1, int64_t s0, int64_t s1) {
     if (n0 <= 1 || n1 <= 1) return (n0 <= 1 || s0 >= 1) && (n1 <= 1 || s1 >= 1);
-    return (s0 >= 1 && (size_t)s1 >= n0 * (size_t)s0) || (s1 >= 1 && (size_t)s0 >= n1 * (size_t)s1);
+    return (s0 >= 1 && (size_t)s1 > (n0 - 1) * (size_t)s0) || (s1 >= 1 && (size_t)s0 > (n1 - 1) * (size_t)s1);
 }
 struct ViewPack {   // the CPU-gathered views of one call
     rrtmgp_workspace *ws;
@@ -1653,7 +1682,7 @@ static int step_t(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmgp_u
     // radiation method reads (prepare_t does; AllSkyRadiation with aerosol_radiation = false on a state with an
     // AerosolState): stage them for the preparation even when no lookup asks for them.
     const bool st_cld = use_cld || (iso && as->cld_frac), st_aero = use_aero || (iso && as->aero_mass);
-    TRY(stage_state(st, &as_lw, st_cld, st_aero, true, ds, use_cld ? nrgh : (st_cld ? (int64_t)INT32_MAX : 1), StateRW{prep, iso}));
+    TRY(stage_state(st, &as_lw, st_cld, st_aero, true, ds, use_cld ? nrgh : 0, StateRW{prep, iso}, use_aero));
     // ... and what only the SW solve writes
     DevState<FT> ds_sw = ds;
     ds_sw.cld_cover = nullptr;
@@ -2001,6 +2030,14 @@ int rrtmgp_hip_workspace_destroy(rrtmgp_workspace *ws) {
 int rrtmgp_hip_workspace_set_stream(rrtmgp_workspace *ws, void *hip_stream) {
     RR_CHECK(ws, "null workspace");
     RR_CHECK(ws->shards.empty(), "a multi-device workspace runs each shard on its own stream");
+    if (ws->stream != (hipStream_t)hip_stream) {
+        // nothing of this workspace may still be running on the stream it leaves: its kernels share the queue counters and
+        // the sweep scratch with whatever the new stream launches next
+        RR_HIP(hipSetDevice(ws->device));
+        RR_HIP(hipStreamSynchronize(ws->stream));
+        if (ws->alt_stream) RR_HIP(hipStreamSynchronize(ws->alt_stream));
+        TRY(queue_check(ws, true));
+    }
     ws->stream = (hipStream_t)hip_stream;  // NULL is the HIP null (legacy default) stream
     return RRTMGP_OK;
 }
@@ -2030,6 +2067,11 @@ int rrtmgp_hip_workspace_last_kernel_ms(rrtmgp_workspace *ws, double *ms) {
     float f = 0;
     RR_HIP(hipEventElapsedTime(&f, ws->ev_start, ws->ev_stop));
     *ms = f;
+    // a timed workspace is a measured / tested one: the cheap place to verify the queue invariant (the timed launch is over;
+    // another lane may still run, so only when the whole workspace is idle)
+    static const bool check = getenv("RRTMGP_HIP_NO_QUEUE_CHECK") == nullptr;
+    if (check && hipStreamQuery(ws->stream) == hipSuccess && (!ws->alt_stream || hipStreamQuery(ws->alt_stream) == hipSuccess))
+        TRY(queue_check(ws, false));
     return RRTMGP_OK;
 }
 

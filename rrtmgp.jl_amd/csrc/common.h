@@ -211,6 +211,9 @@ int scratch_ensure(rrtmgp_workspace *ws, size_t bytes, const Lane *lane = nullpt
 // The kernels leave it zeroed themselves (queue_release, device.h: the last workgroup out resets both counters), so a launch
 // needs no memset in front of it (round 5: two fill kernels + their dependencies were ~15 us of a 250 us step of 512 columns).
 int queue_ensure(rrtmgp_workspace *ws, int lane_idx, int **out);
+// reads the counters of both lanes back (the lanes must be idle) and fails loudly if a kernel left them dirty; `reset_only`:
+// just re-zeroes them (workspace_set_stream).  Every kernel that takes columns from the queue must end with queue_release.
+int queue_check(rrtmgp_workspace *ws, bool reset_only);
 
 // every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
 hipError_t rr_malloc(void **p, size_t bytes);

@@ -25,21 +25,26 @@ __global__ void eval_primitive_kernel(int op, const FT *x, const FT *y, FT *out,
     out[i] = r;
 }
 
+// (device buffers freed on every path: a failing copy or launch returns through the guard)
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)rr_free(p); }
+};
+
 template <typename FT>
 static int eval_primitive(int device, int op, const FT *x, const FT *y, FT *out, int64_t n) {
     RR_HIP(hipSetDevice(device));
-    FT *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    DevBuf dx, dy, dout;
     const size_t bytes = (size_t)n * sizeof(FT);
-    RR_HIP(hipMalloc((void **)&dx, bytes));
-    RR_HIP(hipMalloc((void **)&dout, bytes));
-    if (y) RR_HIP(hipMalloc((void **)&dy, bytes));
-    RR_HIP(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
-    if (y) RR_HIP(hipMemcpy(dy, y, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(eval_primitive_kernel<FT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, dx, dy, dout, n);
+    RR_HIP(rr_malloc(&dx.p, bytes));
+    RR_HIP(rr_malloc(&dout.p, bytes));
+    if (y) RR_HIP(rr_malloc(&dy.p, bytes));
+    RR_HIP(hipMemcpy(dx.p, x, bytes, hipMemcpyHostToDevice));
+    if (y) RR_HIP(hipMemcpy(dy.p, y, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(eval_primitive_kernel<FT>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, (const FT *)dx.p,
+                       (const FT *)dy.p, (FT *)dout.p, n);
     RR_HIP(hipGetLastError());
-    RR_HIP(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dout);
-    if (dy) (void)hipFree(dy);
+    RR_HIP(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return RRTMGP_OK;
 }
 

@@ -696,3 +696,22 @@ def test_device_resident_array_type_is_wired_through_every_descriptor():
     # a resident device is one device
     assert re.search(r"resident && length\(ids\) != 1", JL)
 
+
+
+def test_resident_arrays_are_allocated_on_the_resident_device_not_on_gpu_0():
+    """`ClimaComms.array_type` returns the bare type, so `DA{FT}(undef, ...)` cannot carry the ordinal of
+    `HIPDevice(id; resident = true)`; every HIPArray constructor defaulted to `device = 0`.  Now the constructors default to
+    the module's resident device, which `HIPDevice(id; resident = true)` sets, and `update_fluxes!` refuses resident arrays that
+    do not live on its workspace's GPU."""
+    assert "device::Integer = 0" not in JL
+    ctors = re.findall(r"^(?:    function )?HIPArray(?:\{[^}]*\})?\([^\n]*device::Integer = ([^\)]+)\)", JL, flags=re.M)
+    assert len(ctors) >= 7 and set(ctors) == {"RESIDENT_DEVICE[]"}, ctors
+    assert re.search(r"const RESIDENT_DEVICE = Ref\{Int32\}\(0\)", JL)
+    new_dev = re.search(r"^function new_device_slow\(.*?^end", JL, flags=re.S | re.M).group(0)
+    assert "resident && (RESIDENT_DEVICE[] = Int32(first(ids)))" in new_dev
+    step = re.search(r"^function update_fluxes!\(s::HIPSpectralSolver.*?^end", JL, flags=re.S | re.M).group(0)
+    assert "dev.resident && check_resident_device(dev, as.layerdata" in step
+    chk = re.search(r"^function check_resident_device\(.*?^end", JL, flags=re.S | re.M).group(0)
+    assert "dev.ids[1]" in chk and "wrong_device_slow(have, want)" in chk
+    # similar / copy keep the device of the array they come from
+    assert "Base.similar(a::HIPArray, ::Type{T}, dims::Dims{N}) where {T, N} = HIPArray{T, N}(undef, dims; device = a.device)" in JL

@@ -163,6 +163,16 @@ def test_malformed_views_are_refused():
     assert call(view(p_lev), view(big, s0=2, s1=3)) != 0 and "overlap" in _lib.last_error()
     assert call(view(p_lev), view(big, s0=4, s1=48)) == 0        # a row of a (4, nlay, ncol) array: fine
     assert call(view(p_lev), view(big, s0=8, s1=1)) == 0         # a C-ordered (nlay, ncol) block: fine
+    # `view(A, 1:2:23, :)` of a 23-row parent: 12 rows, stride 2, columns 23 apart - the last row of a column sits
+    # at 22, the next column starts at 23: injective although s1 < n0 * s0 (round 5 refused it)
+    odd = np.zeros(23 * 8)
+    assert call(view(p_lev), view(odd, s0=2, s1=23)) == 0, _lib.last_error()
+    got = odd.reshape(8, 23).T[0:23:2]
+    want = np.zeros((12, 8), order="F")
+    assert call(view(p_lev), view(want)) == 0
+    np.testing.assert_array_equal(got, want)
+    assert (odd.reshape(8, 23).T[1:23:2] == 0).all()          # the rows between stay untouched
+    assert call(view(p_lev), view(odd, s0=2, s1=22)) != 0 and "overlap" in _lib.last_error()   # one short: (11, j) == (0, j + 1)
     # an absent optional array may be a NULL view or a view with a null pointer (what a binding that always passes a struct does)
     assert call(view(p_lev), view(out), view(out, null=True)) == 0
     assert L.rrtmgp_hip_compute_col_gas(ws.handle, _abi.MEM_HOST, 8, 12, None, C.byref(view(out)), C.byref(pd), None, None) != 0

@@ -166,6 +166,24 @@ def test_fused_step_fills_the_boundary_layer_of_arrays_the_method_does_not_read(
 
 
 @pytest.mark.gpu
+def test_clear_sky_step_ignores_cloud_inputs_no_lookup_reads(tables64):
+    """ClearSkyRadiation with the isothermal boundary layer stages the cloud arrays for the preparation only; an
+    `ice_rgh` that no cloud lookup will ever read (0 here) is nobody's business, and the step must not refuse the state for
+    it (round 5 did: "ice_rgh must be in 1..nrghice of the cloud lookup")."""
+    fused, split = _pair(tables64, np.float64, "clear", False, iso=True, interpolation=GA.ArithmeticMean)
+    for s in (fused, split):
+        s.as_.cloud_state.ice_rgh = 0
+    L2.update_fluxes(fused, 3)
+    L2.update_fluxes(split, 3)
+    _assert_same(fused, split, "clear")
+    # ... while a method that does read the clouds still refuses it
+    bad, _ = _pair(tables64, np.float64, "allsky", False)
+    bad.as_.cloud_state.ice_rgh = 0
+    with pytest.raises(Exception, match="ice_rgh"):
+        L2.update_fluxes(bad, 3)
+
+
+@pytest.mark.gpu
 def test_fused_step_matches_the_oracle(tables64):
     """prepare (interpolation, clip, col_dry) + LW + SW + clear-sky pair + net sums against the CPU restatement."""
     t = tables64
