@@ -157,7 +157,7 @@ struct rrtmgp_workspace {
     // pipelined host path (column chunks: chunk c+1 is uploaded while chunk c is being solved)
     std::vector<rrtmgp::DeviceBuffer> stage, stage_alt;
     hipStream_t copy_stream = nullptr;
-    // second compute lane of a SHORT Layer-2 step (api.hip step_t): the SW kernels run on this stream with this sweep
+    // second compute lane of a SHORT Layer-2 step (step.hip step_launch): the SW kernels run on this stream with this sweep
     // scratch while the LW kernels run on `stream`, so that one solver's workgroups fill the slots the other's tail frees
     hipStream_t alt_stream = nullptr;
     rrtmgp::DeviceBuffer alt_scratch;
@@ -218,7 +218,7 @@ int queue_check(rrtmgp_workspace *ws, bool reset_only);
 // every device allocation of the library goes through these two (rrtmgp_hip_allocation_counts)
 hipError_t rr_malloc(void **p, size_t bytes);
 hipError_t rr_free(void *p);
-// page-locked host arrays (process-wide registry, api.hip): is this whole caller array registered (explicitly, or —
+// page-locked host arrays (process-wide registry, runtime.hip): is this whole caller array registered (explicitly, or —
 // opt-in — by the library on first sight)?  `ws` uses it until host_pin_end(ws)
 bool host_pin(rrtmgp_workspace *ws, const void *p, size_t bytes);
 void host_pin_begin(rrtmgp_workspace *ws);

@@ -5,7 +5,7 @@
 // [s*ncol/n, (s+1)*ncol/n), which is one contiguous slab of every state / boundary / flux array because ncol is
 // their slowest dimension.  There is no collective: every shard stages its own slab in, solves it with
 // `col_offset` advanced to its first global column (the McICA stream is keyed by the global column), and
-// stages its fluxes back into the caller's arrays.  The public entry points (api.hip) do the slicing and
+// stages its fluxes back into the caller's arrays.  The public entry points (solve.hip, step.hip, views.hip) do the slicing and
 // re-enter themselves with a shard workspace; this file owns the objects and the fan-out.
 #include <pthread.h>
 #include <sched.h>

@@ -189,7 +189,7 @@ def _check_precision(slv: "_RTE", as_, *lookups):
         if host is not None and np.dtype(host.dtype) != want:
             raise TypeError(f"lookup tables are {np.dtype(host.dtype)}, the workspace was created for {want}")
     nlay, ncol = as_.dims
-    if nlay != slv.ws.nlay or ncol != slv.ws.ncol:  # the rule the library applies (check_common, api.hip)
+    if nlay != slv.ws.nlay or ncol != slv.ws.ncol:  # the rule the library applies (check_common, staging.hip)
         raise ValueError(f"state is (nlay={nlay}, ncol={ncol}); the workspace was created for "
                          f"(nlay={slv.ws.nlay}, ncol={slv.ws.ncol})")
 

@@ -20,7 +20,7 @@ SWN = ("flux_up", "flux_dn", "flux_net", "flux_dn_dir")
 @pytest.mark.parametrize("where", ["host", "host-pipelined", "device", "shards"])
 def test_no_allocation_after_warm_up(tables32, where):
     t = tables32
-    ncol = 16384 if where == "host-pipelined" else 96      # >= 16384 host columns take the chunked pipeline (api.hip)
+    ncol = 16384 if where == "host-pipelined" else 96      # >= 16384 host columns take the chunked pipeline (host.h run_column_pipeline)
     nlay = 24
     as_, lb, sb = S.make_columns(ncol, nlay, np.float32, seed=1, aerosols=True, night_fraction=0.1)
     dev = [0, 0] if where == "shards" else 0

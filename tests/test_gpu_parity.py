@@ -137,7 +137,7 @@ def test_partial_cloud_fraction_masks_match(tables64):
 
 def test_minor_gas_slot_pairs_and_bands_dealt_to_wavefronts(monkeypatch):
     """kminor travels in slot pairs (one gather per T plane serves two contributors) and, with whole 16-g-point bands, the
-    bands are dealt to the wavefronts by slot count (csrc/api.hip build_gas).  Bands with 0 slots, odd counts and more than
+    bands are dealt to the wavefronts by slot count (csrc/lookups.hip build_gas).  Bands with 0 slots, odd counts and more than
     8 slots (the pairs beyond the four gathered ahead of the wait) against the oracle, and the dealt order against the
     lookup's own order: which lane solves a g-point enters only the order of the g-point sums."""
     lw = S.make_gas_lookup("lw", np.float64, seed=3, n_bnd=9, gpt_per_bnd=16, n_minor_lower=(0, 11), n_minor_upper=(0, 7))
@@ -549,7 +549,7 @@ def test_host_pipeline_with_band_fluxes_and_incident_flux(tables32):
 
 def test_host_pipeline_matches_device_resident_solve(tables32):
     """Large host-memory solves are cut into column chunks whose uploads overlap the previous chunk's
-    kernel (api.hip, "pipelined host path").  Same bits as the single-launch device-resident solve,
+    kernel (host.h, run_column_pipeline).  Same bits as the single-launch device-resident solve,
     including the McICA sample (keyed by the global column) and the per-column diagnostics."""
     import torch
     t = tables32
