@@ -640,6 +640,8 @@ def main():
                 "f64": run_leg("f64", ["--dtype", "f64"]),
                 "aerosols": run_leg("aerosols", ["--aerosols"]),
                 "clear_sky_diag": run_leg("clear_sky_diag", ["--clear-sky-diag", "one-pass"]),
+                # ... with MERRA aerosols: AllSkyRadiationWithClearSkyDiagnostics(aerosol_radiation = true), what ClimaAtmos runs
+                "clear_sky_diag_aerosols": run_leg("clear_sky_diag_aerosols", ["--clear-sky-diag", "one-pass", "--aerosols"]),
                 "ncol_1048576": run_leg("ncol_1048576", ["--tile", "8", "--steps", "3", "--warmup", "1"]),
                 # BASELINE config 2's solvers and precision at bench size: the reference's clear-sky pairing, Float64
                 "noscat_clear_f64": run_leg("noscat_clear_f64", ["--lw-solver", "noscat", "--angles", "1", "--no-clouds",

@@ -17,6 +17,8 @@ PASSES=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
         "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC"
         "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum"
         "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE GRBM_COUNT")
+# PROFILE_LITE=1: kernel trace + the two HBM passes only (the variant legs of bench.py: profiles/latest_<leg>.json)
+if [ -n "${PROFILE_LITE:-}" ]; then PASSES=("FETCH_SIZE" "WRITE_SIZE"); fi
 for pass in "${PASSES[@]}"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 200 rocprofv3 --pmc $pass --kernel-trace $SEL -d $OUT/pmc_$name -o bench -- $BENCH > $OUT/pmc_$name.log 2>&1 || echo "pass failed: $pass" >> $OUT/failed.txt
