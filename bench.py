@@ -150,6 +150,14 @@ def run_leg(name, extra, env=None, timeout=600):
         return {"error": repr(ex)[:300]}
 
 
+def rank_columns(ncol_total, rank, world):
+    """Strong scaling: the contiguous range [lo, hi) of the job's columns that `rank` of `world` solves — the ranges of
+    rrtmgp.jl_amd/sharding.py (balanced, the first ranks take the remainder), which is also how the library shards a
+    multi-device workspace.  A pure function (tests/test_sharding.py checks it at world size 8 without a GPU)."""
+    from rrtmgp_jl_amd import sharding
+    return sharding.shard_range(ncol_total, rank, world)
+
+
 def self_launch(n):
     """Re-executes this command line under torch.distributed.run with `n` ranks on 127.0.0.1 (a free port)."""
     import socket
@@ -332,7 +340,7 @@ def main():
     if strong:
         if single or args.tile != 1:
             raise SystemExit("--scaling strong is the one-process-per-GPU path without --tile")
-        c_lo, c_hi = args.ncol_total * rank // world, args.ncol_total * (rank + 1) // world   # rrtmgp.jl_amd/sharding.py ranges
+        c_lo, c_hi = rank_columns(args.ncol_total, rank, world)
         args.ncol = c_hi - c_lo
         if args.ncol < 1:
             raise SystemExit("--ncol-total is smaller than the number of ranks")

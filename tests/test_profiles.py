@@ -73,3 +73,36 @@ def test_roofline_fraction_is_reproducible_from_the_committed_profile():
     v = bench.kernel_valu(dom, pj["kernels"][dom]["avg_us"] / 1e3, ncol, nlay, 256 if dom.startswith("lw") else 224)
     assert abs(v["frac"] - prof["frac"]) < 1e-9 and r["bound"] == "valu"
 
+
+
+LEG_KERNELS = {"clear_sky_diag": ("lw_solve_kernel", "sw_solve_kernel"), "clear_sky_diag_aerosols": ("lw_solve_kernel", "sw_solve_kernel"),
+               "f64": ("lw_solve_kernel", "sw_solve_kernel"), "noscat_clear_f64": ("lw_noscat_kernel", "sw_solve_kernel"),
+               "aerosols": ("lw_solve_kernel", "sw_solve_kernel")}
+
+
+@pytest.mark.parametrize("leg", sorted(LEG_KERNELS))
+def test_variant_legs_have_a_committed_profile_that_prices_their_kernels(leg):
+    """Round 6: the production (one-pass diagnostic, with and without aerosols), Float64 and no-scattering instances have
+    their own rocprofv3 summaries (tools/profile_legs.sh -> profiles/latest_<leg>.json); bench.py's `leg_profile` turns the
+    kernel-trace averages into the leg's `profiled` block with the formula of `roofline.profiled`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rocprof_summary import kernel_source_sha256
+    path = os.path.join(ROOT, "profiles", f"latest_{leg}.json")
+    assert os.path.exists(path)
+    pj = json.load(open(path))
+    assert os.path.exists(os.path.join(ROOT, "profiles", pj["source"].replace("prof_", "") + "_kernels.txt"))
+    for k in LEG_KERNELS[leg]:
+        assert pj["kernels"][k]["avg_us"] > 1000 and pj["kernels"][k]["FETCH_SIZE"] > 0 and pj["kernels"][k]["WRITE_SIZE"] > 0
+    bench = _bench()
+    f64 = "f64" in leg
+    nlay = 60 if leg == "noscat_clear_f64" else 64
+    peak = bench.FP64_VALU_PEAK_TFLOPS if f64 else bench.VALU_PEAK_TFLOPS
+    lw_cell = (bench.LW_NOSCAT_FLOPS_PER_CELL + bench.LW_NOSCAT_FLOPS_PER_ANGLE) if leg == "noscat_clear_f64" else bench.LW_FLOPS_PER_CELL
+    rec = bench.leg_profile(leg, bench.NCOL_PER_GPU, nlay, 256, 224, peak, lw_cell)
+    if pj["kernel_source_sha256"] != kernel_source_sha256(ROOT):
+        assert "withheld" in rec["note"]
+        pytest.skip("kernel sources changed after this leg was profiled: bench.py withholds the block")
+    assert set(rec["kernels"]) == set(LEG_KERNELS[leg])
+    for name, r in rec["kernels"].items():
+        assert 0.05 < r["frac"] < 0.6 and r["traffic"] > 1e10, (name, r)
+    assert abs(rec["step"]["kernel_ms"] - sum(r["kernel_ms"] for r in rec["kernels"].values())) < 1e-9

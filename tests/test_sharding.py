@@ -141,6 +141,76 @@ def test_bench_bare_command_starts_its_own_ranks():
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
 
 
+def _worker8(rank, world, port, q, ncol):
+    """One rank of a world-size-8 job on BASELINE config 4's column counts: its contiguous range through the oracle, the host
+    gather, bench.py's agreement on the step time (MAX over ranks) and its per-rank audit record."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        nlay = 6
+        sw = S.make_gas_lookup("sw", np.float64, seed=7, n_bnd=2, gpt_per_bnd=[4, 4])
+        cs = S.make_cloud_lookup("sw", 2, seed=7)
+        as_, _, sb = S.make_columns(ncol, nlay, np.float64, seed=5, random_cld_frac=True, n_bnd_lw=2, n_bnd_sw=2, night_fraction=0.2)
+        f_sw, (lo, hi) = sharding.solve_sharded(lambda a, b, col_offset: O.solve_sw(a, b, sw, cs, seed=9, col_offset=col_offset),
+                                                as_, sb, ncol, rank, world)
+        g = sharding.gather_columns(f_sw.flux_dn, ncol)
+        ok = True
+        if rank == 0:   # the unsharded solve, once
+            ok = bool(np.array_equal(g, O.solve_sw(as_, sb, sw, cs, seed=9).flux_dn))
+        every = [None] * world
+        dist.all_gather_object(every, {"rank": rank, "columns": hi - lo, "lo": lo})
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ok, float(t.item()), (lo, hi), [e["columns"] for e in every]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncol", [4096, 4097])
+def test_world_size_8_gloo_on_config4_column_counts(ncol):
+    """BASELINE config 4 strong-scales 4096 columns over 8 GPUs: 512-column ranges; 4097 gives the ragged case (513 + 7 x 512).
+    Eight gloo ranks on CPU: ranges cover the job, the gathered fluxes equal the unsharded solve bit for bit (the McICA stream
+    is keyed by the global column), every rank sees every rank's column count, MAX over ranks is the last rank's time."""
+    import torch.multiprocessing as mp
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, ncol)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    widths = [512 + (1 if r < ncol - 4096 else 0) for r in range(world)]
+    lo = 0
+    for r, (rank, ok, tmax, rng, counts) in enumerate(res):
+        assert rank == r and ok and tmax == 8.0 and counts == widths
+        assert rng == (lo, lo + widths[r])
+        lo += widths[r]
+    assert lo == ncol
+
+
+def test_bench_strong_scaling_ranges_are_the_sharding_ranges():
+    """bench.py --scaling strong hands rank r the range of rrtmgp.jl_amd/sharding.py (what the library's multi-device
+    workspace uses too): 8 ranks on config 4's 4096 columns, ragged 4097, fewer columns than ranks."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [bench.rank_columns(4096, r, 8) for r in range(8)] == [(512 * r, 512 * (r + 1)) for r in range(8)]
+    rs = [bench.rank_columns(4097, r, 8) for r in range(8)]
+    assert rs[0] == (0, 513) and rs[1] == (513, 1025) and rs[-1] == (3585, 4097)
+    assert [hi - lo for lo, hi in (bench.rank_columns(5, r, 8) for r in range(8))] == [1, 1, 1, 1, 1, 0, 0, 0]   # bench.py refuses the empty ranks
+
+
 def test_bench_self_launch_command(monkeypatch):
     """The re-exec of a bare `--gpus N` command: torch.distributed.run, one node, N ranks, loopback rendezvous, the
     original arguments unchanged (no GPU needed: the child process is not started)."""
@@ -184,6 +254,23 @@ def test_bench_single_process_fan_out_on_one_gpu():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["ncol_per_gpu"] == 4096 and "ONE host process" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_single_process_eight_shards_on_one_gpu():
+    """`bench.py --gpus 8 --single-process`: the library's fan-out with EIGHT shards (eight parked host threads, eight
+    streams, replicated lookups), all wrapped onto the one GPU of the test box: the path `HIPDevice(0:7)` takes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--single-process", "--steps", "2",
+                        "--warmup", "1", "--ncol", "512", "--nlay", "72", "--aerosols", "--cpu-sample", "0", "--no-legs"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["ncol_per_gpu"] == 512 and "8 shards in one process" in d["config"]["workload"]
+    assert abs(d["value"] - 8 * 512 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
 
 
 @pytest.mark.gpu
