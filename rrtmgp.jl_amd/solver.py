@@ -193,6 +193,9 @@ class RRTMGPSolver:
 
     # ---- update_net_fluxes!, update_fluxes.jl:165-194 ----------------------------------------------
     def update_net_fluxes(self):
+        # The UNFUSED path only (`fused=False`, the reference's four separate steps; the fused step forms both sums inside
+        # rrtmgp_hip_update_fluxes).  A mirror of the reference's host broadcast `net .= lw .+ sw` (Fluxes.jl:407-424): numpy
+        # for host arrays, torch for resident ones - torch is plumbing for the caller's device arrays here, not the product path.
         if self.resident:
             import torch
             add = torch.add
