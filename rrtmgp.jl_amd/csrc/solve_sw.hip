@@ -87,7 +87,7 @@ constexpr int DB = 16;  // levels per batch of the light sweeps
 // workgroup past a quarter of the CU's LDS (Float32, 71-80 layers): 4 resident workgroups instead of 3.  Float32 DIAG
 // instances: once more with 8-layer chunks AND at 128 VGPRs (4 waves per SIMD), taken when that admits one more workgroup.
 template <typename FT, bool TWOSTREAM, bool BAND, bool DIAG, int CA = -1, bool HALF = false>
-__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR_DIAG_MIN_WAVES) : RR_MIN_WAVES) : HALF ? RR_F64_HALF_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
+__global__ void __launch_bounds__(256, (sizeof(FT) == 4 ? (DIAG ? (HALF ? 4 : RR_DIAG_MIN_WAVES) : (HALF ? RR_SW_HALF_WAVES : RR_MIN_WAVES)) : HALF ? RR_F64_HALF_WAVES : 2)) sw_solve_kernel(const SwArgs<FT> a) {
     extern __shared__ __align__(16) char smem[];
     constexpr int CHK = HALF ? half_chunk_layers<FT>() : chunk_layers(CA, DIAG);  // layers per chunk of LDS records
     ColShared<FT, CHK> sh;
@@ -464,7 +464,8 @@ int launch_sw(rrtmgp_workspace *ws, int twostream, const DevGas<FT> &lk, const D
     static const bool no_half = getenv("RRTMGP_HIP_NO_HALF_CHUNKS") != nullptr;  // A/B switch
     // Float64: the 8-layer instances are compiled for RR_F64_HALF_WAVES waves per SIMD (device.h) and taken when their
     // records let that many workgroups share the CU's LDS
-    constexpr size_t lds_cap = sizeof(FT) == 4 ? 40960 : (160 * 1024) / RR_F64_HALF_WAVES;
+    static const size_t lds_cap_f32 = getenv("RRTMGP_HIP_SW_LDS_CAP") ? (size_t)atol(getenv("RRTMGP_HIP_SW_LDS_CAP")) : 40960;   // A/B switch
+    const size_t lds_cap = sizeof(FT) == 4 ? lds_cap_f32 : (160 * 1024) / RR_F64_HALF_WAVES;
     ColShared<FT, half_chunk_layers<FT>()> dummy_half;
     // (round 5 sweep, tools/experiments/half_rule_sweep.sh, profiles/r05_half_rule_sweep_ab.txt: 80 layers +6.9 %, 84 +6.1 %, 88 +4.5 %,
     // 96 layers LW 11.49 -> 10.98 ms but SW 13.04 -> 13.12: the limit was 80 for both kernels since round 2; now 88 here)

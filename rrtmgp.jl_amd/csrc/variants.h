@@ -23,6 +23,9 @@
 #ifndef RR_F64_HALF_CHUNK  // ... and their layers per chunk of LDS records
 #define RR_F64_HALF_CHUNK 8
 #endif
+#ifndef RR_SW_HALF_WAVES  // ... the Float32 shortwave main instances with 8-layer chunks (5 = 96 VGPRs: a fifth workgroup per CU; experiment)
+#define RR_SW_HALF_WAVES RR_MIN_WAVES
+#endif
 #ifndef RR_ACC_ATOMIC  // SW layer loop: g-point sums by 4 DPP steps + one LDS add (1) or 6 DPP steps + store (0)
 #define RR_ACC_ATOMIC 1
 #endif
@@ -77,13 +80,19 @@
 #else
 #define RR_HAS_RR_F64_HALF_CHUNK ""
 #endif
+#if RR_SW_HALF_WAVES != RR_MIN_WAVES
+#define RR_HAS_RR_SW_HALF_WAVES " RR_SW_HALF_WAVES=" RR_STR(RR_SW_HALF_WAVES)
+#define RR_ANY_EXPERIMENT 1
+#else
+#define RR_HAS_RR_SW_HALF_WAVES ""
+#endif
 #if RR_SWEEP_NT != 0
 #define RR_HAS_RR_SWEEP_NT " RR_SWEEP_NT=" RR_STR(RR_SWEEP_NT)
 #define RR_ANY_EXPERIMENT 1
 #else
 #define RR_HAS_RR_SWEEP_NT ""
 #endif
-#define RR_BUILD_FLAGS (RR_HAS_RR_SWEEP_NT RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK RR_HAS_RR_LIBM_F64)
+#define RR_BUILD_FLAGS (RR_HAS_RR_SWEEP_NT RR_BUILD_FLAGS_PRECISE RR_HAS_RR_MIN_WAVES RR_HAS_RR_DIAG_MIN_WAVES RR_HAS_RR_ACC_ATOMIC RR_HAS_RR_F64_HALF_WAVES RR_HAS_RR_F64_HALF_CHUNK RR_HAS_RR_LIBM_F64 RR_HAS_RR_SW_HALF_WAVES)
 #if defined(RR_ANY_EXPERIMENT) && !defined(RR_EXPERIMENTS)
 #error "non-default tuning values are experiments: build them with `make variant NAME=... EXTRA=...` (adds -DRR_EXPERIMENTS), never into the shipped library"
 #endif
