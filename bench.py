@@ -484,8 +484,9 @@ def main():
     up, sdn = torch.as_tensor(slv_lw.flux.flux_up), torch.as_tensor(slv_sw.flux.flux_dn)
     if args.host:
         up, sdn = up.T, sdn.T  # numpy (nlev, ncol) -> (ncol, nlev) like the device tensors
-    assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
-    assert args.lw_only or bool(torch.isfinite(sdn).all())
+    if not os.environ.get("RRTMGP_BENCH_NO_CHECK"):   # (timing-only experiment libraries give wrong results by construction)
+        assert bool(torch.isfinite(up).all()) and bool((up[:, 0] > 0).all())
+        assert args.lw_only or bool(torch.isfinite(sdn).all())
 
     lw_cell = (LW_NOSCAT_FLOPS_PER_CELL + LW_NOSCAT_FLOPS_PER_ANGLE * args.angles) if noscat else LW_FLOPS_PER_CELL
     flops_col = nlay * (lw.n_gpt * lw_cell + (0.0 if args.lw_only else sw.n_gpt * SW_FLOPS_PER_CELL))
