@@ -493,6 +493,36 @@ typedef struct rrtmgp_update_fluxes_args {
 
 int rrtmgp_hip_update_fluxes(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_args *args);
 
+/* update_fluxes!(s, seedval) for GrayRadiation (src/api/update_fluxes.jl:223-233 with :19-23 / :81-85, the gray methods of
+ * update_lw_fluxes! / update_sw_fluxes!), in ONE call:
+ *     prepare_atmosphere!(s) (gray form: interpolation, isothermal layer, pressure clip; src/api/grid_adaptation.jl:147-156,
+ *     215-227)  ->  gray LW solve (K5 / K6)  ->  gray SW solve (K7 / K8)  ->  net_flux = lw_net + sw_net,
+ * with the gray state staged once.  The reference runs this through its generic Layer-2 path, whose presentation copies and
+ * net sum are array broadcasts (Fluxes.jl:408,424): on device-resident arrays of a host language without a GPU array package
+ * (ext/RRTMGPHIPExt.jl `HIPArray`) there is nothing to run those, so the step is offered whole — `flux_lw` / `flux_sw` take
+ * the presentation arrays ((nlev, ncol), RRTMGP_LAYOUT_NLEV_NCOL) exactly as in rrtmgp_hip_update_fluxes.
+ *  - `lw_solver`: RRTMGP_LW_TWOSTREAM / RRTMGP_LW_NOSCAT; `sw_twostream`: 1 = TwoStreamSWRTE, 0 = NoScatSWRTE (gray radiation
+ *    may pair a non-scattering shortwave solver, src/api/solver.jl:110-112).
+ *  - `net_flux` FT (nlev, ncol) or NULL, memory kind of `flux_lw`; `prepare` NULL = the state is already prepared;
+ *    `opts->metric_scaling` = deep_atmosphere_inverse_scaling (n_gauss_angles must be <= 1: gray radiation uses one angle).
+ * The bits are those of the separate calls (rrtmgp_hip_prepare_atmosphere_gray, rrtmgp_hip_rte_*_solve_gray + a host sum).
+ * Multi-device workspaces shard the columns; host arrays are staged, device arrays used in place. */
+typedef struct rrtmgp_update_fluxes_gray_args {
+    const rrtmgp_gray_state *as;    /* s.as */
+    const rrtmgp_lw_bcs *bcs_lw;    /* s.lws.bcs: sfc_emis (1, ncol), inc_flux (ncol) or NULL */
+    const rrtmgp_sw_bcs *bcs_sw;    /* s.sws.bcs: albedos (1, ncol) */
+    const rrtmgp_flux_out *flux_lw; /* flux_dn_dir NULL */
+    const rrtmgp_flux_out *flux_sw;
+    void *net_flux;                 /* FT (nlev, ncol) or NULL */
+    const rrtmgp_params *params;    /* needed with `prepare` */
+    const rrtmgp_prepare_opts *prepare; /* or NULL */
+    const rrtmgp_solve_opts *opts;  /* or NULL */
+    int32_t lw_solver;
+    int32_t sw_twostream;
+} rrtmgp_update_fluxes_gray_args;
+
+int rrtmgp_hip_update_fluxes_gray(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_gray_args *args);
+
 /* Bytes this workspace (all shards) has moved host -> device and device -> host since it was created: what a host-array
  * call costs on PCIe (bench.py reports bytes per column of the Layer-2 step; tests count the staging of strided views). */
 int rrtmgp_hip_workspace_transfer_bytes(const rrtmgp_workspace *ws, uint64_t *h2d, uint64_t *d2h);
@@ -625,7 +655,8 @@ const char *rrtmgp_hip_version(void);
 const char *rrtmgp_hip_build_flags(void);
 /* sizeof() of ABI struct number `which` as compiled into the library (0 minor_desc,
  * 1 gas_lookup_desc, 2 cloud_lookup_desc, 3 aerosol_lookup_desc, 4 atmos_state, 5 lw_bcs,
- * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d, 13 update_fluxes_args); -1 otherwise.  Lets a
+ * 6 sw_bcs, 7 flux_out, 8 solve_opts, 9 gray_state, 10 params, 11 prepare_opts, 12 view2d, 13 update_fluxes_args,
+ * 14 update_fluxes_gray_args); -1 otherwise.  Lets a
  * foreign-language binding verify its struct mirror at load time. */
 int rrtmgp_hip_abi_sizeof(int which);
 

@@ -108,6 +108,14 @@ class UpdateFluxesArgs(C.Structure):
                 ("lw_solver", i32), ("_pad", i32)]
 
 
+class UpdateFluxesGrayArgs(C.Structure):
+    """rrtmgp_update_fluxes_gray_args: update_fluxes! for GrayRadiation in one call."""
+    _fields_ = [("as_", C.POINTER(GrayState)), ("bcs_lw", C.POINTER(LwBcs)), ("bcs_sw", C.POINTER(SwBcs)),
+                ("flux_lw", C.POINTER(FluxOut)), ("flux_sw", C.POINTER(FluxOut)), ("net_flux", vp),
+                ("params", C.POINTER(Params)), ("prepare", C.POINTER(PrepareOpts)), ("opts", C.POINTER(SolveOpts)),
+                ("lw_solver", i32), ("sw_twostream", i32)]
+
+
 LW_TWOSTREAM, LW_NOSCAT = 1, 0
 PREP_INTERPOLATE, PREP_ISOTHERMAL, PREP_CLIP, PREP_COL_DRY, PREP_ALL = 1, 2, 4, 8, 15
 PREP_REL_HUM = 16   # optional extra step: relative humidity refreshed in the same launch

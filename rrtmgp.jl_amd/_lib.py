@@ -55,6 +55,7 @@ EXPORTS = {
     "rrtmgp_hip_prepare_atmosphere_gray": (C.c_int, [_P, C.POINTER(_abi.GrayState), C.POINTER(_abi.Params),
                                                      C.POINTER(_abi.PrepareOpts)]),
     "rrtmgp_hip_update_fluxes": (C.c_int, [_P, C.POINTER(_abi.UpdateFluxesArgs)]),
+    "rrtmgp_hip_update_fluxes_gray": (C.c_int, [_P, C.POINTER(_abi.UpdateFluxesGrayArgs)]),
     "rrtmgp_hip_workspace_transfer_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rrtmgp_hip_gas_lookup_create_multi": (C.c_int, [C.POINTER(_abi.GasLookupDesc), C.POINTER(C.c_int32), C.c_int,
                                                      C.POINTER(_P)]),
@@ -84,7 +85,7 @@ EXPORTS = {
 
 ABI_STRUCTS = [_abi.MinorDesc, _abi.GasLookupDesc, _abi.CloudLookupDesc, _abi.AerosolLookupDesc, _abi.AtmosState,
                _abi.LwBcs, _abi.SwBcs, _abi.FluxOut, _abi.SolveOpts, _abi.GrayState, _abi.Params, _abi.PrepareOpts,
-               _abi.View2D, _abi.UpdateFluxesArgs]
+               _abi.View2D, _abi.UpdateFluxesArgs, _abi.UpdateFluxesGrayArgs]
 
 
 class RRTMGPHipError(RuntimeError):

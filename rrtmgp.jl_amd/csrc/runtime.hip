@@ -515,6 +515,7 @@ int rrtmgp_hip_abi_sizeof(int which) {
         case 11: return (int)sizeof(rrtmgp_prepare_opts);
         case 12: return (int)sizeof(rrtmgp_view2d);
         case 13: return (int)sizeof(rrtmgp_update_fluxes_args);
+        case 14: return (int)sizeof(rrtmgp_update_fluxes_gray_args);
         default: return -1;
     }
 }

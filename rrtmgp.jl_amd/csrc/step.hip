@@ -336,6 +336,69 @@ static int step_host(rrtmgp_workspace *ws, const StepLookups<FT> &L, const rrtmg
                                });
 }
 
+// ---- the gray step: update_fluxes!(s) for GrayRadiation in one call (include/rrtmgp_hip.h) ------------------------------
+// The gray state crosses once ([prepare] reads and writes p / T of layers and levels), then gray LW -> gray SW -> net sum on
+// the workspace stream.  Same launches, in the same order, as the separate entry points: same bits.
+template <typename FT>
+static int step_gray_t(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_gray_args *a) {
+    const rrtmgp_gray_state *gs = a->as;
+    const rrtmgp_lw_bcs *bl = a->bcs_lw;
+    const rrtmgp_sw_bcs *bs = a->bcs_sw;
+    const rrtmgp_prepare_opts *po = a->prepare;
+    const size_t E = sizeof(FT), ncol = gs->ncol, nlay = gs->nlay, nlev = nlay + 1;
+    const bool prep = po != nullptr;
+    const int twostream_lw = a->lw_solver == RRTMGP_LW_TWOSTREAM, twostream_sw = a->sw_twostream != 0;
+    RR_CHECK(!a->opts || a->opts->n_gauss_angles <= 1, "gray radiation is solved with a single quadrature angle");
+    RR_CHECK(gs->lat && gs->p_lay && gs->p_lev && gs->t_lay && gs->t_lev && gs->t_sfc && bl->sfc_emis, "gray LW: missing array");
+    RR_CHECK(bs->cos_zenith && bs->toa_flux && a->flux_sw->flux_dn_dir, "gray SW: missing array");
+    RR_CHECK(!twostream_sw || (bs->sfc_alb_direct && bs->sfc_alb_diffuse), "gray SW two-stream: surface albedos are required");
+    RR_CHECK(a->flux_lw->layout == a->flux_sw->layout, "flux_lw and flux_sw must share one layout");
+    RR_CHECK(!prep || a->params, "update_fluxes (gray): `params` is required with `prepare`");
+    Stager st{ws, {}};
+    const int mem = gs->mem;
+    const FT *lat, *p_lay, *p_lev, *t_lay, *t_lev, *t_sfc, *emis, *inc, *mu0, *toa, *adir, *adif;
+    TRY(st.in(mem, S_LAT, gs->lat, ncol * E, (const void **)&lat));
+    TRY(st.io(prep, mem, S_PLAY, gs->p_lay, nlay * ncol * E, (const void **)&p_lay));
+    TRY(st.io(prep, mem, S_PLEV, gs->p_lev, nlev * ncol * E, (const void **)&p_lev));
+    TRY(st.io(prep, mem, S_TLAY, gs->t_lay, nlay * ncol * E, (const void **)&t_lay));
+    TRY(st.io(prep, mem, S_TLEV, gs->t_lev, nlev * ncol * E, (const void **)&t_lev));
+    TRY(st.in(mem, S_TSFC, gs->t_sfc, ncol * E, (const void **)&t_sfc));
+    PrepView<FT> pv{};
+    if (prep) {
+        pv.ncol = (int)ncol; pv.nlay = (int)nlay; pv.ls = 1;
+        pv.p_lay = const_cast<FT *>(p_lay); pv.t_lay = const_cast<FT *>(t_lay);
+        pv.p_lev = const_cast<FT *>(p_lev); pv.t_lev = const_cast<FT *>(t_lev);
+        pv.t_sfc = t_sfc;
+        TRY(st.in(po->z_mem, S_ZC, po->center_z, nlay * ncol * E, (const void **)&pv.center_z));
+        TRY(st.in(po->z_mem, S_ZF, po->face_z, nlev * ncol * E, (const void **)&pv.face_z));
+    }
+    TRY(st.in(bl->mem, S_LW_BC0, bl->sfc_emis, ncol * E, (const void **)&emis));
+    TRY(st.in(bl->mem, S_LW_BC1, bl->inc_flux, ncol * E, (const void **)&inc));
+    TRY(st.in(bs->mem, S_BC0, bs->cos_zenith, ncol * E, (const void **)&mu0));
+    TRY(st.in(bs->mem, S_BC1, bs->toa_flux, ncol * E, (const void **)&toa));
+    TRY(st.in(bs->mem, S_BC2, bs->sfc_alb_direct, ncol * E, (const void **)&adir));
+    TRY(st.in(bs->mem, S_BC3, bs->sfc_alb_diffuse, ncol * E, (const void **)&adif));
+    DevFlux<FT> fl_lw, fl_sw;
+    TRY(stage_flux(st, a->flux_lw, a->opts, ncol, nlev, false, fl_lw));
+    TRY(stage_flux(st, a->flux_sw, a->opts, ncol, nlev, true, fl_sw, 0, S_X_FLUX_UP - S_FLUX_UP, fl_lw.metric));
+    if (!fl_lw.metric) fl_sw.metric = nullptr;
+    FT *net = nullptr;
+    TRY(st.out(a->flux_lw->mem, S_NET, a->net_flux, ncol * nlev * E, (void **)&net));
+    if (prep) {
+        rrtmgp_prepare_opts og = *po;
+        og.steps &= ~RRTMGP_PREP_COL_DRY;   // a gray state has no col_dry (rrtmgp_hip_prepare_atmosphere_gray)
+        TRY(launch_prepare<FT>(ws, pv, *a->params, og, true));
+    }
+    GrayArgs ga;
+    ga.otp_kind = gs->otp_kind;
+    for (int i = 0; i < 5; i++) ga.otp[i] = gs->otp[i];
+    ga.stefan = gs->stefan;
+    TRY(launch_gray_lw<FT>(ws, twostream_lw, (int)ncol, (int)nlay, ga, lat, p_lay, p_lev, t_lay, t_lev, t_sfc, emis, inc, fl_lw));
+    TRY(launch_gray_sw<FT>(ws, twostream_sw, (int)ncol, (int)nlay, ga, p_lay, p_lev, mu0, toa, adir, adif, fl_sw));
+    if (net) TRY(launch_net_sum<FT>(ws, fl_lw.net, fl_sw.net, net, ncol, nlev, fl_lw.layout, fl_lw.ld, fl_sw.ld));
+    return st.finish();
+}
+
 }  // namespace rrtmgp
 
 using namespace rrtmgp;
@@ -388,6 +451,50 @@ int rrtmgp_hip_update_fluxes(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_ar
     TRY(check_common(ws, a->lookup_lw, 0, a->lookup_lw_cld, a->lookup_lw_aero, a->as));
     TRY(check_common(ws, a->lookup_sw, 1, a->lookup_sw_cld, a->lookup_sw_aero, a->as));
     return step_dispatch(ws, a);
+}
+
+int rrtmgp_hip_update_fluxes_gray(rrtmgp_workspace *ws, const rrtmgp_update_fluxes_gray_args *a) {
+    RR_CHECK(ws && a, "null argument");
+    RR_CHECK(a->as && a->bcs_lw && a->bcs_sw && a->flux_lw && a->flux_sw, "update_fluxes (gray): state, boundary conditions and flux outputs are required");
+    RR_CHECK(a->lw_solver == RRTMGP_LW_TWOSTREAM || a->lw_solver == RRTMGP_LW_NOSCAT, "lw_solver must be RRTMGP_LW_TWOSTREAM or RRTMGP_LW_NOSCAT");
+    RR_CHECK(a->as->ncol == ws->ncol && a->as->nlay == ws->nlay, "state dimensions differ from the workspace");
+    RR_CHECK(a->as->otp_kind == 0 || a->as->otp_kind == 1, "unknown gray optical-thickness kind");
+    const rrtmgp_solve_opts *o = a->opts;
+    if (!ws->shards.empty()) {
+        TRY(check_multi(ws, a->as->mem, a->bcs_lw->mem, a->flux_lw, o, nullptr));
+        TRY(check_multi(ws, a->as->mem, a->bcs_sw->mem, a->flux_sw, o, nullptr));
+        const bool dev_arrays = a->as->mem == RRTMGP_MEM_DEVICE || a->bcs_lw->mem == RRTMGP_MEM_DEVICE || a->bcs_sw->mem == RRTMGP_MEM_DEVICE ||
+                                a->flux_lw->mem == RRTMGP_MEM_DEVICE || a->flux_sw->mem == RRTMGP_MEM_DEVICE ||
+                                (o && o->metric_scaling && o->metric_mem == RRTMGP_MEM_DEVICE);
+        const size_t E = (size_t)ws->ftype, ncol = (size_t)a->as->ncol, nlay = (size_t)a->as->nlay, nlev = nlay + 1;
+        return multi_run(ws, [&](rrtmgp_workspace *sw, size_t c0, size_t nc) -> int {
+            const ColumnSlice sl{E, c0};
+            rrtmgp_update_fluxes_gray_args c = *a;
+            rrtmgp_gray_state g = *a->as;
+            rrtmgp_lw_bcs bl = *a->bcs_lw;
+            rrtmgp_sw_bcs bs = *a->bcs_sw;
+            rrtmgp_flux_out fl = *a->flux_lw, fs = *a->flux_sw;
+            rrtmgp_solve_opts so{};
+            if (o) so = *o; else so.n_gauss_angles = 1;
+            rrtmgp_prepare_opts po{};
+            slice_gray(g, sl, nc);
+            bl.sfc_emis = sl.adv(bl.sfc_emis, 1); bl.inc_flux = sl.adv(bl.inc_flux, 1);
+            slice_sw_bcs(bs, sl, 1);
+            slice_flux_arrays(fl, sl, nlev, ncol);
+            slice_flux_arrays(fs, sl, nlev, ncol);
+            slice_opts(so, sl, nlev);
+            c.net_flux = sl.adv(c.net_flux, nlev);
+            if (a->prepare) {
+                po = *a->prepare;
+                po.center_z = sl.adv(po.center_z, nlay); po.face_z = sl.adv(po.face_z, nlev);
+                c.prepare = &po;
+            }
+            c.as = &g; c.bcs_lw = &bl; c.bcs_sw = &bs; c.flux_lw = &fl; c.flux_sw = &fs; c.opts = &so;
+            return rrtmgp_hip_update_fluxes_gray(sw, &c);
+        }, dev_arrays);
+    }
+    RR_HIP(hipSetDevice(ws->device));
+    return ws->ftype == RRTMGP_F32 ? step_gray_t<float>(ws, a) : step_gray_t<double>(ws, a);
 }
 
 }  // extern "C"

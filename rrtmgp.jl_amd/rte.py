@@ -294,6 +294,43 @@ def update_fluxes(lws: _RTE, sws: _RTE, as_, lookup_lw, lookup_sw, lookup_lw_cld
     return lws.flux, sws.flux
 
 
+def update_fluxes_gray(lws: _RTE, sws: _RTE, as_, metric_scaling=None, net_flux=None, params=None,
+                       prepare: Optional[_abi.PrepareOpts] = None):
+    """update_fluxes! for GrayRadiation in ONE call of the library (`rrtmgp_hip_update_fluxes_gray`): the gray state crosses
+    once, then [`prepare` kernel] -> gray LW -> gray SW -> `net_flux = lw net + sw net` (update_fluxes.jl:223-233 with the gray
+    methods :19-23 / :81-85).  What a resident solver needs: the reference's generic path forms the presentation copies and
+    the net sum with array broadcasts."""
+    if lws.ws is not sws.ws:
+        raise ValueError("update_fluxes_gray: the longwave and the shortwave solver must share one Workspace")
+    if not isinstance(as_, GrayAtmosphericState):
+        raise TypeError("update_fluxes_gray takes a GrayAtmosphericState")
+    _check_precision(lws, as_)
+    _check_precision(sws, as_)
+    a = _abi.UpdateFluxesGrayArgs()
+    dg, bl, bs = as_.desc(), lws.bcs.desc(), sws.bcs.desc()
+    fl, fs = lws.flux.desc(), sws.flux.desc()
+    o = _opts(1, metric_scaling, 0, 0)
+    a.as_, a.bcs_lw, a.bcs_sw, a.flux_lw, a.flux_sw, a.opts = (C.pointer(dg), C.pointer(bl), C.pointer(bs), C.pointer(fl),
+                                                               C.pointer(fs), C.pointer(o))
+    if net_flux is not None:
+        ptr, mem = array_ptr(net_flux)
+        if mem != fl.mem:
+            raise ValueError("update_fluxes_gray: net_flux must live where the flux buffers live")
+        if tuple(julia_shape(net_flux)) != (lws.ws.nlay + 1, lws.ws.ncol):
+            raise ValueError("update_fluxes_gray: net_flux must be (nlev, ncol)")
+        a.net_flux = ptr
+    keep = None
+    if prepare is not None:
+        if params is None:
+            raise ValueError("update_fluxes_gray: `params` is required with `prepare`")
+        keep = params.desc()
+        a.params, a.prepare = C.pointer(keep), C.pointer(prepare)
+    a.lw_solver = _abi.LW_TWOSTREAM if lws.twostream else _abi.LW_NOSCAT
+    a.sw_twostream = 1 if sws.twostream else 0
+    _lib.check(_lib.lib().rrtmgp_hip_update_fluxes_gray(lws.ws.handle, C.byref(a)), "update_fluxes_gray")
+    return lws.flux, sws.flux
+
+
 def _check_extents(ws: Workspace, what: str, **arrays):
     for name, (a, want) in arrays.items():
         if a is None:

@@ -140,7 +140,7 @@ class RRTMGPSolver:
         self.clear_flux_lw = Flux.allocate(ncol, nlay + 1, dtype, sw=False, device=fdev) if diag else None
         self.clear_flux_sw = Flux.allocate(ncol, nlay + 1, dtype, sw=True, device=fdev) if diag else None
         self.clear_net_flux_buffer = zeros() if diag else None
-        self.fused = bool(fused) and not gray
+        self.fused = bool(fused)   # gray radiation too (round 6: rrtmgp_hip_update_fluxes_gray)
         self._seed = 0       # key of the counter-based McICA stream of the current update_fluxes call
         self._rng_state = 0  # host generator the per-call keys are drawn from (the reference's global `Random` state)
 
@@ -278,6 +278,12 @@ class RRTMGPSolver:
         front of the two solves, the clear-sky diagnostic rides in the all-sky launches, and `net_flux` / `clear_net_flux`
         are summed on the device (update_fluxes.jl:223-233)."""
         m, lk = self.radiation_method, self.lookups
+        if isinstance(m, GrayRadiation):
+            prep = grid_adaptation.prepare_atmosphere_opts(self.as_, None, self.interpolation, self.bottom_extrapolation,
+                                                           self.isothermal_boundary_layer, self.center_z, self.face_z)
+            rte.update_fluxes_gray(self.lws, self.sws, self.as_, metric_scaling=self.deep_atmosphere_inverse_scaling,
+                                   net_flux=self.net_flux_buffer, params=self.params, prepare=prep)
+            return
         clouds = not isinstance(m, ClearSkyRadiation)
         aero = m.aerosol_radiation
         prep = grid_adaptation.prepare_atmosphere_opts(self.as_, lk.lookup_lw, self.interpolation, self.bottom_extrapolation,

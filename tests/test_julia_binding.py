@@ -17,7 +17,8 @@ PAIRS = {"MinorDesc": _abi.MinorDesc, "GasLookupDesc": _abi.GasLookupDesc, "Clou
          "AerosolLookupDesc": _abi.AerosolLookupDesc, "AtmosStateDesc": _abi.AtmosState, "LwBcsDesc": _abi.LwBcs,
          "SwBcsDesc": _abi.SwBcs, "FluxOutDesc": _abi.FluxOut, "SolveOpts": _abi.SolveOpts,
          "GrayStateDesc": _abi.GrayState, "ParamsDesc": _abi.Params, "PrepareOpts": _abi.PrepareOpts,
-         "View2D": _abi.View2D, "UpdateFluxesArgs": _abi.UpdateFluxesArgs}
+         "View2D": _abi.View2D, "UpdateFluxesArgs": _abi.UpdateFluxesArgs,
+         "UpdateFluxesGrayArgs": _abi.UpdateFluxesGrayArgs}
 SIZES = {"Int32": 4, "Int64": 8, "UInt64": 8, "Float64": 8, "P": 8, "Ptr{Int64}": 8, "MinorDesc": C.sizeof(_abi.MinorDesc),
          "NTuple{5, Float64}": 40}
 
@@ -226,7 +227,7 @@ FIELD_HINTS.update({
     ("TwoStreamLWRTE", "band_flux"): ["FluxBand"], ("TwoStreamSWRTE", "band_flux"): ["FluxBand"],
     ("LookupBundle", "lookup_lw"): ["LookUpLW"], ("LookupBundle", "lookup_sw"): ["LookUpSW"],
 })
-TYPE_ALIASES = {"HIPSpectralSolver": ["RRTMGPSolver"]}
+TYPE_ALIASES = {"HIPSpectralSolver": ["RRTMGPSolver"], "HIPGraySolver": ["RRTMGPSolver"]}
 
 
 def _bad_fields(src):
@@ -467,7 +468,8 @@ _STRUCT2JL = {"rrtmgp_gas_lookup_desc": "GasLookupDesc", "rrtmgp_cloud_lookup_de
               "rrtmgp_aerosol_lookup_desc": "AerosolLookupDesc", "rrtmgp_atmos_state": "AtmosStateDesc",
               "rrtmgp_lw_bcs": "LwBcsDesc", "rrtmgp_sw_bcs": "SwBcsDesc", "rrtmgp_flux_out": "FluxOutDesc",
               "rrtmgp_solve_opts": "SolveOpts", "rrtmgp_gray_state": "GrayStateDesc", "rrtmgp_params": "ParamsDesc",
-              "rrtmgp_prepare_opts": "PrepareOpts", "rrtmgp_view2d": "View2D", "rrtmgp_update_fluxes_args": "UpdateFluxesArgs"}
+              "rrtmgp_prepare_opts": "PrepareOpts", "rrtmgp_view2d": "View2D", "rrtmgp_update_fluxes_args": "UpdateFluxesArgs",
+              "rrtmgp_update_fluxes_gray_args": "UpdateFluxesGrayArgs"}
 
 
 def test_ccall_argument_types_match_the_header():
@@ -715,3 +717,21 @@ def test_resident_arrays_are_allocated_on_the_resident_device_not_on_gpu_0():
     assert "dev.ids[1]" in chk and "wrong_device_slow(have, want)" in chk
     # similar / copy keep the device of the array they come from
     assert "Base.similar(a::HIPArray, ::Type{T}, dims::Dims{N}) where {T, N} = HIPArray{T, N}(undef, dims; device = a.device)" in JL
+
+
+def test_gray_step_override_is_one_library_call_and_is_field_checked():
+    """Round 6: `update_fluxes!(s::HIPGraySolver)` = ONE ccall of rrtmgp_hip_update_fluxes_gray with the presentation arrays,
+    so gray radiation runs on device-resident HIPArrays (the generic method's presentation copies / net sum are broadcasts).
+    The solver alias is followed by the field checker like the spectral one."""
+    m = re.search(r"^function update_fluxes!\(s::HIPGraySolver, seedval = nothing\)\n(.*?)^end", JL, flags=re.S | re.M)
+    assert m, "no gray override"
+    body = m.group(1)
+    assert body.count("ccall(") == 1 and ":rrtmgp_hip_update_fluxes_gray" in body
+    assert "presented_desc(s.presented_flux_lw, nothing, nothing)" in body and "ptr(s.net_flux_buffer)" in body
+    assert "GC.@preserve s sc" in body and "check_resident_device(dev, gs.p_lay" in body
+    assert "const HIPGraySolver = RRTMGP.RRTMGPSolver{<:HIPGrid, <:RRTMGP.GrayRadiation}" in JL
+    broken = JL.replace("set!(sc.flux_sw, presented_desc(s.presented_flux_sw, nothing, nothing))",
+                        "set!(sc.flux_sw, presented_desc(s.presented_sw, nothing, nothing))", 1)
+    assert broken != JL and any(why == "RRTMGPSolver has no field presented_sw" for _, _, why in _bad_fields(broken)), _bad_fields(broken)
+    broken = JL.replace("gray_desc(gs, RP.Stefan(s.params))", "gray_desc(gs, RP.Stefan(s.param_set))", 1)
+    assert broken != JL and any(why == "RRTMGPSolver has no field param_set" for _, _, why in _bad_fields(broken))

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from rrtmgp_jl_amd import _abi, _lib, synthetic as S
+from rrtmgp_jl_amd import _abi, _lib, rte, synthetic as S
 from rrtmgp_jl_amd import grid_adaptation as GA
 from rrtmgp_jl_amd import solver as L2
 from rrtmgp_jl_amd.states import TEST_PARAMETERS, Flux
@@ -376,3 +376,74 @@ print("DIGEST", h.hexdigest())
         digests[name] = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0]
     assert len(set(digests.values())) == 1, digests
     _ = hashlib
+
+
+# ---- the gray step (rrtmgp_hip_update_fluxes_gray) --------------------------------------------------------------------
+def _gray_solver(fused, op_lw="twostream", op_sw="twostream", iso=False, interpolation=GA.NoInterpolation, resident=False,
+                 device=0, FT=np.float64, ncol=9, nlay=30, metric=True):
+    from oracle import oracle as O
+    from rrtmgp_jl_amd.states import GrayOpticalThicknessOGorman2008, LwBCs, RRTMGPParameters, SwBCs
+    params = RRTMGPParameters()
+    gs = O.setup_gray_as_pr_grid(nlay, np.linspace(-70.0, 70.0, ncol), 100000.0, 9000.0, GrayOpticalThicknessOGorman2008(), params, FT)
+    if interpolation != GA.NoInterpolation:   # the levels are outputs then
+        gs.p_lev[1:] = np.nan
+        gs.t_lev[1:] = np.nan
+    lb = LwBCs(np.asfortranarray(np.full((1, ncol), 0.97, FT)), np.asfortranarray(np.linspace(0.0, 3.0, ncol).astype(FT)))
+    mu0 = np.full(ncol, 0.6, FT); mu0[2] = -0.1
+    sb = SwBCs(mu0, np.full(ncol, 1407.679, FT), np.asfortranarray(np.full((1, ncol), 0.12, FT)),
+               np.asfortranarray(np.full((1, ncol), 0.1, FT)))
+    ms = np.asfortranarray(np.random.default_rng(4).uniform(0.97, 1.03, (nlay + 1, ncol)).astype(FT)) if metric else None
+    return L2.RRTMGPSolver(L2.GrayRadiation(), params, lb, sb, gs, op_lw=op_lw, op_sw=op_sw, fused=fused, resident=resident,
+                           device=device, isothermal_boundary_layer=iso, interpolation=interpolation,
+                           deep_atmosphere_inverse_scaling=ms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+@pytest.mark.parametrize("op_lw,op_sw", [("twostream", "twostream"), ("onescalar", "twostream"), ("twostream", "onescalar"),
+                                         ("onescalar", "onescalar")])
+def test_gray_step_equals_the_separate_calls(FT, op_lw, op_sw):
+    """update_fluxes! for GrayRadiation as ONE library call (prepare + gray LW + gray SW + net sum) against the reference's
+    four steps as separate calls: the same bits in every getter, with incident flux, a night column and the metric factors."""
+    fused, split = _gray_solver(True, op_lw, op_sw, FT=FT), _gray_solver(False, op_lw, op_sw, FT=FT)
+    L2.update_fluxes(fused)
+    L2.update_fluxes(split)
+    for g in GETTERS:
+        x, y = getattr(L2, g)(fused), getattr(L2, g)(split)
+        assert np.isfinite(x).all() and (np.abs(x).max() > 0 or (g == "sw_flux_up" and op_sw == "onescalar")), g   # (no-scattering SW: nothing goes up)
+        np.testing.assert_array_equal(x, y, err_msg=g)
+    np.testing.assert_array_equal(L2.net_flux(fused), L2.lw_flux_net(fused) + L2.sw_flux_net(fused))
+    assert (L2.sw_flux_dn(fused)[:, 2] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interpolation,iso", [(GA.ArithmeticMean, True), (GA.GeometricMean, False), (GA.NoInterpolation, True)])
+def test_gray_step_with_preparation_and_on_resident_and_sharded_arrays(interpolation, iso):
+    """The preparation cascade of a gray state (level interpolation, isothermal boundary layer, pressure clip) runs as a kernel
+    in front of the two gray solves; host arrays, device-resident arrays (nothing crosses PCIe) and a three-shard workspace
+    give the bits of the separate calls, prepared state included."""
+    from rrtmgp_jl_amd.states import to_host
+    ref = _gray_solver(False, iso=iso, interpolation=interpolation)
+    L2.update_fluxes(ref)
+    for kw in (dict(), dict(resident=True), dict(device=[0, 0, 0])):
+        s = _gray_solver(True, iso=iso, interpolation=interpolation, **kw)
+        L2.update_fluxes(s)
+        for g in GETTERS:
+            np.testing.assert_array_equal(to_host(getattr(L2, g)(s)), getattr(L2, g)(ref), err_msg=f"{g} {kw}")
+        for n in ("p_lay", "p_lev", "t_lay", "t_lev"):
+            np.testing.assert_array_equal(to_host(getattr(s.as_, n)), getattr(ref.as_, n), err_msg=f"{n} {kw}")
+        if kw.get("resident"):
+            assert s.lws.ws.transfer_bytes() == (0, 0)
+
+
+@pytest.mark.gpu
+def test_gray_step_argument_errors():
+    import ctypes as C
+    from rrtmgp_jl_amd import _abi, _lib
+    s = _gray_solver(True)
+    a = _abi.UpdateFluxesGrayArgs()
+    assert _lib.lib().rrtmgp_hip_update_fluxes_gray(s.lws.ws.handle, C.byref(a)) != 0 and "required" in _lib.last_error()
+    assert _lib.lib().rrtmgp_hip_update_fluxes_gray(None, C.byref(a)) != 0
+    other = rte.Workspace(3, 30, np.float64)
+    with pytest.raises(Exception, match="share one Workspace|dimensions"):
+        rte.update_fluxes_gray(s.lws, rte.TwoStreamSWRTE(9, 30, np.float64, s.sws.bcs, workspace=other), s.as_)
