@@ -122,6 +122,12 @@ class RRTMGPSolver:
         dtype = as_.dtype
         self.nlay, self.ncol, self.dtype = nlay, ncol, dtype
         ws = rte.Workspace(ncol, nlay, dtype, device)  # LW and SW share the library scratch
+        if resident:
+            # Device arrays are used in place and the library's work is ordered on the WORKSPACE stream: a resident solver runs
+            # it on torch's current stream, behind the fills / copies that made its arrays and in front of whatever the caller
+            # does with the getters' views next.  (On its private non-blocking stream nothing ordered the first launch behind the
+            # NaN fill of the flux buffers: a gray step, which uploads no lookup in between, could lose that race - round 6.)
+            ws.use_torch_stream()
         lw_cls = rte.TwoStreamLWRTE if op_lw == "twostream" else rte.NoScatLWRTE
         sw_cls = rte.TwoStreamSWRTE if op_sw == "twostream" else rte.NoScatSWRTE
         # compute buffers ARE the (nlev, ncol) presentation: update_presentation! is a no-op here
