@@ -345,6 +345,94 @@ def test_linear_table_longwave_isothermal(tables64, backend, ft, solver):
     assert np.abs(dn - want_dn).max() < tol, np.abs(dn - want_dn).max()
 
 
+def absorbing_particles(cld, aero, seed):
+    """Cloud and aerosol lookups that only absorb (ssa = 0) with closed-form extinction: cloud extinction affine in the
+    particle size (so the size interpolation of cloud_optics.jl:170-182 is exact), one extinction per band for every aerosol
+    species, bin and humidity (so the sum over species does not depend on the MERRA index conventions).  Returns
+    (cloud lookup, aerosol lookup, coefficients)."""
+    r = np.random.default_rng(seed)
+    nband, nrgh, nl, ni = (int(x) for x in cld.dims[:4])
+    b = cld.bounds.astype(np.float64)
+    rl, ri = np.linspace(b[0], b[1], nl), np.linspace(b[2], b[3], ni)
+    co = dict(l0=r.uniform(0.02, 0.06, nband), l1=r.uniform(-1e-3, 2e-3, nband), i0=r.uniform(0.01, 0.04, (nband, nrgh)),
+              i1=r.uniform(-1e-4, 3e-4, (nband, nrgh)), aer=r.uniform(2e2, 2e3, nband), bounds=b)
+    liq, ice = np.zeros_like(cld.liqdata, dtype=np.float64), np.zeros_like(cld.icedata, dtype=np.float64)
+    liq[:nl] = co["l0"][None, :] + co["l1"][None, :] * rl[:, None]
+    ice[:ni] = co["i0"][None] + co["i1"][None] * ri[:, None, None]
+    liq[2 * nl:], ice[2 * ni:] = 0.8, 0.7                       # asymmetry: irrelevant without scattering
+    assert (liq[:nl] > 0).all() and (ice[:ni] > 0).all()
+    cld2 = dataclasses.replace(cld, liqdata=F(liq), icedata=F(ice))
+    kw = {}
+    for name in ("dust", "sea_salt", "sulfate", "black_carbon_rh", "black_carbon", "organic_carbon_rh", "organic_carbon"):
+        t = np.zeros_like(getattr(aero, name), dtype=np.float64)
+        t[0] = co["aer"]                                        # (ext, ssa, asy) x ... x band: band is the last axis
+        t[2] = 0.6
+        kw[name] = F(t)
+    return cld2, dataclasses.replace(aero, **kw), co
+
+
+def closed_form_particle_tau(co, as_):
+    """tau[layer, column, band] of the absorbing clouds (overcast where cloudy) and aerosols, from the state alone."""
+    cs, a = as_.cloud_state, as_.aerosol_state
+    eps = np.finfo(as_.dtype).eps
+    b = co["bounds"]
+    rl = np.clip(cs.cld_r_eff_liq.astype(np.float64), b[0], b[1])[..., None]
+    ri = np.clip(cs.cld_r_eff_ice.astype(np.float64), b[2], b[3])[..., None]
+    pl, pi = cs.cld_path_liq.astype(np.float64)[..., None], cs.cld_path_ice.astype(np.float64)[..., None]
+    rg = int(cs.ice_rgh) - 1
+    cloudy = (cs.cld_frac > 0)[..., None]
+    tau = np.where(cloudy & (pl > eps), (co["l0"] + co["l1"] * rl) * pl, 0.0) + \
+        np.where(cloudy & (pi > eps), (co["i0"][:, rg] + co["i1"][:, rg] * ri) * pi, 0.0)
+    mass = np.where(a.aero_mass > 0, a.aero_mass, 0).astype(np.float64).sum(axis=0)      # (nlay, ncol)
+    return tau + mass[..., None] * co["aer"]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("ft", [np.float64, np.float32])
+@pytest.mark.parametrize("solver", ["sw", "lw2stream", "lwnoscat"])
+def test_linear_tables_with_absorbing_clouds_and_aerosols(tables64, backend, ft, solver):
+    """(c) with particles: affine gas tables + absorbing clouds (extinction affine in particle size, overcast McICA) + absorbing
+    aerosols.  Every optical depth is closed-form, nothing scatters: Beer-Lambert shortwave, isothermal longwave.  Pins the
+    cloud size interpolation, the cloud / aerosol increments of both optics flavours (TwoStream and OneScalar) and the McICA
+    mask of overcast layers, without the oracle."""
+    if backend == "twin" and ft == np.float32:
+        pytest.skip("the numpy twin computes in Float64")
+    ncol, nlay = sizes(backend, big=(4096, 73))
+    kind = "sw" if solver == "sw" else "lw"
+    base = tables64["sw"] if kind == "sw" else _const_planck_fraction(tables64["lw"])
+    lk64, co = affine_lookup(base, seed=45, kscale=2e-23 if kind == "sw" else 3e-22)
+    cld64, aero64, pco = absorbing_particles(tables64["cld_" + kind], tables64["aero_" + kind], seed=46)
+    lk, cld, aero = lk64.astype(ft), cld64.astype(ft), aero64.astype(ft)
+    as_, lb, sb = S.make_columns(ncol, nlay, ft, seed=38, clouds=True, cld_frac=1.0, aerosols=True)
+    bnd = lk.major_gpt2bnd - 1
+    if solver == "sw":
+        up, dn, dr = run_sw(backend, as_, sb, lk, cld, aero)
+        tau = closed_form_tau(lk, co, as_) + closed_form_particle_tau(pco, as_)[..., bnd]
+        mu0 = sb.cos_zenith.astype(np.float64)
+        top = (sb.toa_flux.astype(np.float64) * mu0)[:, None] * lk.solar_src_scaled.astype(np.float64)[None, :]
+        beam = top[None] * np.exp(-_cum_from_top(tau) / mu0[None, :, None])
+        refl = beam[0] * sb.sfc_alb_direct.astype(np.float64)[bnd, :].T
+        want_up, want_dir = (refl[None] * np.exp(-2.0 * _cum_from_sfc(tau))).sum(axis=2), beam.sum(axis=2)
+        tol = 5e-8 if ft == np.float64 else 4e-2    # (1.1e-8 on the GPU at 4 096 x 73: its Float64 exp is a 2-ulp form, 73 cumulative optical depths)
+        assert (closed_form_particle_tau(pco, as_).sum(axis=0).max(axis=1) > 0.5).any()      # the clouds matter
+        for name, got, want in (("dir", dr, want_dir), ("dn", dn, want_dir), ("up", up, want_up)):
+            assert np.abs(got - want).max() < tol, (name, np.abs(got - want).max())
+        return
+    t0 = 267.0
+    as_ = _isothermal(as_, ft(t0))
+    lb = LwBCs(F(np.ones_like(lb.sfc_emis)), None)
+    up, dn = run_lw(backend, as_, lb, lk, cld, aero, twostream=solver == "lw2stream")
+    tau = closed_form_tau(lk, co, as_) + closed_form_particle_tau(pco, as_)[..., bnd]
+    it = int(np.nonzero(lk.t_planck == t0)[0][0])
+    B = (lk64.tot_planck[it, bnd] * lk64.planck_fraction[0, 0, 0, :])[None, None, :]
+    D = 1.66 if solver == "lw2stream" else 1.0 / 0.6096748751
+    want_dn = np.pi * (B * (1.0 - np.exp(-D * _cum_from_top(tau)))).sum(axis=2)
+    want_up = np.full_like(want_dn, np.pi * lk64.tot_planck[it].sum())
+    tol = 1e-8 if ft == np.float64 else 1e-3
+    assert np.abs(up - want_up).max() < tol, np.abs(up - want_up).max()
+    assert np.abs(dn - want_dn).max() < tol, np.abs(dn - want_dn).max()
+
+
 # ---- (d) optically thin / thick limits of the longwave sources ----------------------------------------------------------
 def _scaled(as_, factor):
     ld = as_.layerdata.copy(order="F")
