@@ -602,7 +602,9 @@ int rrtmgp_hip_host_registered_count(void);
  * `HIPArray`, ext/RRTMGPHIPExt.jl; the reference gets this from CUDA.jl's CuArray, ext/RRTMGPCUDAExt.jl:1-66): allocation,
  * release, blocking copies (ordered behind everything queued on the device) and byte fills on device `device`.  A pointer
  * from rrtmgp_hip_device_malloc is what the descriptors take with `mem = RRTMGP_MEM_DEVICE`.  Not part of the library's own
- * allocation accounting (rrtmgp_hip_allocation_counts). */
+ * allocation accounting (rrtmgp_hip_allocation_counts).  The copies and fills synchronise the WHOLE device (that is what orders
+ * them behind solves queued on any workspace's private stream): meant for setup, checkpoints and getters between radiation
+ * steps, not for a per-step path - a host that drives several workspaces concurrently serialises them with every such call. */
 enum { RRTMGP_COPY_H2D = 1, RRTMGP_COPY_D2H = 2, RRTMGP_COPY_D2D = 3 };
 int rrtmgp_hip_device_malloc(int device, size_t bytes, void **out);
 int rrtmgp_hip_device_free(int device, void *ptr);
