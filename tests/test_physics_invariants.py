@@ -487,3 +487,57 @@ def test_longwave_thick_limit(tables64, backend, solver):
     local = np.pi * (planck(as_.t_lev)[..., bnd] * pf).sum(axis=2)
     np.testing.assert_allclose(up[1:-1], local[1:-1], rtol=2e-4)
     np.testing.assert_allclose(dn[1:-1], local[1:-1], rtol=2e-4)
+
+
+# ---- (e) the other kernel instances under the same invariants -----------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", [np.float64, np.float32])
+@pytest.mark.parametrize("solver", ["sw", "lw"])
+@pytest.mark.parametrize("instance", ["diag", "band"])      # the library rejects both in one launch (EINVAL)
+def test_layer_splitting_on_the_diag_and_band_instances(tables64, ft, solver, instance):
+    """The one-pass clear-sky twin (DIAG) and the per-band outputs (BAND) are separate template instances of the solve
+    kernels (solve_lw.hip / solve_sw.hip): the layer-splitting invariant of (a) on their extra outputs, plus what the
+    outputs mean — band fluxes sum to the broadband flux, the clear-sky pair equals a solve without the cloud lookup."""
+    from rrtmgp_jl_amd import rte
+    from rrtmgp_jl_amd.states import Flux
+    ncol, nlay = 512, 64
+    is_sw = solver == "sw"
+    lk = (tables64["sw"] if is_sw else _const_planck_fraction(tables64["lw"])).astype(ft)
+    cld = tables64["cld_sw" if is_sw else "cld_lw"].astype(ft)
+    aero = tables64["aero_sw" if is_sw else "aero_lw"].astype(ft)
+    as_, lb, sb = S.make_columns(ncol, nlay, ft, seed=41, clouds=True, aerosols=True, cld_frac=1.0)
+    if not is_sw:
+        as_ = _isothermal(as_, ft(268.0))
+    cls, solve, bcs = (rte.TwoStreamSWRTE, rte.solve_sw, sb) if is_sw else (rte.TwoStreamLWRTE, rte.solve_lw, lb)
+    names = ("flux_up", "flux_dn") + (("flux_dn_dir",) if is_sw else ())
+
+    def run(state):
+        nl, nc = state.dims
+        slv = cls(nc, nl, ft, bcs, n_bnd_band_flux=lk.n_bnd if "band" in instance else 0)
+        clear = Flux.allocate(nc, nl + 1, ft, sw=is_sw) if "diag" in instance else None
+        solve(slv, state, lk, cld, aero, seed=9, clear_flux=clear)
+        out = {"all": [np.asarray(getattr(slv.flux, n), np.float64) for n in names]}
+        if clear is not None:
+            out["clear"] = [np.asarray(getattr(clear, n), np.float64) for n in names]
+        if slv.band_flux is not None:
+            out["band"] = [np.asarray(getattr(slv.band_flux, n), np.float64) for n in ("flux_up", "flux_dn")]
+        return out
+
+    one, two = run(as_), run(split_layers(as_))
+    # same budgets as (a): Float64 the rounding of 2 x 64 layers with the 2-ulp exp, Float32 the rounding of twice as many layers
+    tol = 2e-8 if ft == np.float64 else (2.5e-2 if is_sw else 2e-3)
+    assert one["all"][1].max() > 100.0
+    for key in one:
+        for a, b in zip(one[key], two[key]):
+            d = np.abs(a - b[0::2]).max()
+            assert d < tol, (key, d)
+    sum_tol = 1e-9 if ft == np.float64 else 2e-3
+    if "band" in one:
+        for a, b in zip(one["band"], one["all"]):
+            assert np.abs(a.sum(axis=2) - b).max() < sum_tol * max(1.0, b.max() / 100.0)
+    if "clear" in one:
+        plain = cls(ncol, nlay, ft, bcs)
+        solve(plain, dataclasses.replace(as_, cloud_state=None), lk, None, aero, seed=9)
+        for n, a in zip(names, one["clear"]):
+            assert np.abs(a - np.asarray(getattr(plain.flux, n), np.float64)).max() < sum_tol * 15, n
+        assert np.abs(one["clear"][0] - one["all"][0]).max() > 1.0     # the clouds do something
